@@ -1,0 +1,49 @@
+# Builds the product library (HIP kernels + C ABI + host mirror) for gfx950, the oracle, and
+# the headless driver.  `python -c "import __graft_entry__ as g; g.build()"` drives this.
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+CSRC    := path_tracer_amd/csrc
+HOST    := path_tracer_amd/host
+LIBDIR  := path_tracer_amd/lib
+LIB     := $(LIBDIR)/libpt_amd.so
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude
+OBJS    := build/pt_api.o build/pt_path_kernel.o build/pt_f64_kernels.o build/pt_builtin_scenes.o
+
+all: $(LIB) oracle tools/pt_headless
+
+$(LIB): $(OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+build/pt_api.o: $(CSRC)/pt_api.cpp $(CSRC)/pt_device.h include/pt.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+build/pt_path_kernel.o: $(CSRC)/pt_path_kernel.hip $(CSRC)/pt_device.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+# FP64 kernels: no FMA contraction, so every operation is one IEEE double op (bit-exact ids)
+build/pt_f64_kernels.o: $(CSRC)/pt_f64_kernels.hip $(CSRC)/pt_device.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
+
+build/pt_builtin_scenes.o: $(HOST)/pt_builtin_scenes.cpp include/pt_host.hpp include/pt.h
+	@mkdir -p build
+	g++ -O2 -fPIC -std=c++17 -Wall -ffp-contract=off -Iinclude -c $< -o $@
+
+oracle:
+	$(MAKE) -C oracle
+
+tools/pt_headless: tools/pt_headless.cpp include/pt_host.hpp include/pt.h $(LIB)
+	g++ -O2 -std=c++17 -Wall -Iinclude -o $@ tools/pt_headless.cpp -L$(LIBDIR) -lpt_amd -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
+
+isa: $(CSRC)/pt_path_kernel.hip $(CSRC)/pt_device.h
+	@mkdir -p build/isa
+	$(HIPCC) $(HIPFLAGS) -save-temps=obj -Rpass-analysis=kernel-resource-usage -c $(CSRC)/pt_path_kernel.hip -o build/isa/pt_path_kernel.o 2> build/isa/resource_usage.txt || true
+
+clean:
+	rm -rf build $(LIB) tools/pt_headless
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean isa

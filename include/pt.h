@@ -1,0 +1,268 @@
+/*
+ * pt.h — C ABI of the MI355X-native per-pixel render path.
+ *
+ * This is the drop-in boundary for the L3→L2 line of the reference
+ * (Qervas/path_tracer): every symbol main.cu / main.cpp call across that line
+ * has a counterpart here.  Plain pointers and sizes only; no C++ / torch types;
+ * no exception crosses the ABI.  Every entry point returns 0 on success and a
+ * negative PT_ERR_* code otherwise; pt_last_error() returns a thread-local
+ * human-readable message for the last failing call.
+ *
+ * Citations are `path:line` under the reference tree (cuda_pathtracer/… or
+ * cpu_pathtracer/…).
+ *
+ * Threading: one context per GPU.  A context is not thread-safe; different
+ * contexts may be driven from different threads.  All device work of a context
+ * is enqueued on the context's stream (its own, or the one given to
+ * pt_set_stream); nothing synchronises with the host unless documented.
+ */
+#ifndef PT_H_
+#define PT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- errors -- */
+#define PT_OK 0
+#define PT_ERR_INVALID (-1)   /* bad argument / inconsistent sizes            */
+#define PT_ERR_HIP (-2)       /* a HIP runtime call failed                     */
+#define PT_ERR_STATE (-3)     /* call order (no scene / camera / frame yet)    */
+#define PT_ERR_CAPACITY (-4)  /* request exceeds a documented maximum          */
+
+/* ------------------------------------------------------------- materials -- */
+/* Tags of the reference's five polymorphic materials
+ * (cuda_pathtracer/include/Material.cuh:36,82,125,178,235). */
+#define PT_MAT_LAMBERTIAN 0u
+#define PT_MAT_METAL 1u
+#define PT_MAT_DIELECTRIC 2u
+#define PT_MAT_GLOSSY 3u
+#define PT_MAT_EMISSIVE 4u
+
+/* ----------------------------------------------------------------- scene -- */
+/*
+ * Flattened scene, structure-of-arrays.  Replaces the GPUSphere / GPUPlane /
+ * GPUTriangle AoS upload and the eight device-side material objects
+ * (cuda_pathtracer/src/main.cu:214-278, include/raytracer_kernel.cuh:21-48,
+ * include/MaterialFactory.cuh:41-75).  Array order within each primitive class
+ * is insertion order; the kernels test all spheres, then all planes, then all
+ * triangles with a strict `<` (raytracer_kernel.cu:157-181).
+ *
+ * All real-valued inputs are double so that the cpu_pathtracer scene
+ * (cpu_pathtracer/src/main.cpp:63-131, double literals) is carried exactly; the
+ * library keeps a double copy for the FP64 kernels (primary ids, `direct`
+ * integrator) and a float copy for the FP32 `path` kernel.
+ *
+ * `*_obj` is the object's insertion index over ALL objects of the scene (the
+ * "object id" reported by pt_primary_ids); `*_mat` indexes the material table.
+ * `sph_emissive[i]` != 0 marks a sphere on which makeEmissive() was called
+ * (ImplicitObject.cuh:31-35 / ImplicitObject.h:30-34); sph_em_* is then
+ * colour*strength.  The caller keeps ownership of every array; they are copied
+ * during pt_upload_scene.
+ */
+typedef struct PtSceneSoA {
+    uint32_t num_spheres;
+    uint32_t num_planes;
+    uint32_t num_triangles;
+    uint32_t num_materials;
+
+    /* spheres: Sphere_t(center, radius, material), ImplicitObject.cuh:71 */
+    const double *sph_cx, *sph_cy, *sph_cz, *sph_r;
+    const uint32_t *sph_mat, *sph_obj, *sph_emissive;
+    const double *sph_em_r, *sph_em_g, *sph_em_b;
+
+    /* planes: Plane_t(point, normal, material), ImplicitObject.cuh:162
+     * (normal is normalised by the library, as the constructor does). */
+    const double *pl_px, *pl_py, *pl_pz, *pl_nx, *pl_ny, *pl_nz;
+    const uint32_t *pl_mat, *pl_obj;
+
+    /* triangles: Triangle_t(v0, v1, v2, material), Polygon.cuh:48
+     * (geometric normal cross(v1-v0, v2-v0) normalised by the library). */
+    const double *tri_v0x, *tri_v0y, *tri_v0z;
+    const double *tri_v1x, *tri_v1y, *tri_v1z;
+    const double *tri_v2x, *tri_v2y, *tri_v2z;
+    const uint32_t *tri_mat, *tri_obj;
+
+    /* materials: Lambertian(albedo) / Metal(albedo, roughness) /
+     * Dielectric(ior) / Glossy(albedo, roughness, metallic) /
+     * Emissive(colour, strength) — Material.cuh:41,92,147,185,241.
+     * mat_em_* = colour*strength of an Emissive material. */
+    const uint32_t *mat_type;
+    const double *mat_albedo_r, *mat_albedo_g, *mat_albedo_b;
+    const double *mat_roughness, *mat_metallic, *mat_ior;
+    const double *mat_em_r, *mat_em_g, *mat_em_b;
+} PtSceneSoA;
+
+/* Capacity of one scene (the reference's __constant__ arrays hold 32/32/128,
+ * raytracer_kernel.cu:12-18; BASELINE config 5 needs 4096 spheres). */
+#define PT_MAX_SPHERES 65536u
+#define PT_MAX_PLANES 4096u
+#define PT_MAX_TRIANGLES 65536u
+#define PT_MAX_MATERIALS 65536u
+
+/* ---------------------------------------------------------------- camera -- */
+/* Which ray-generation formula the kernels use. */
+#define PT_CAMERA_CUDA 0u /* generateCameraRay, raytracer_kernel.cu:245-265,287-288 */
+#define PT_CAMERA_CPU 1u  /* Camera::getRayForPixel, cpu_pathtracer/include/Camera.h:124-142
+                             (including its vertical-offset behaviour) */
+
+/* Camera(origin, target, up, Settings{fov, aspect_ratio, aperture, focus_dist,
+ * width, height, use_dof}) — Camera.cuh:12-20,39 / Camera.h:18-26,54.
+ * The library derives the look-at basis exactly as Camera_t::initialize
+ * (Camera.cu:3-23, float) or Camera::initialize (Camera.h:65-85, double).
+ * `up` is used as given when `normalize_up` is 0 (Camera::lookAt(from,to,up),
+ * Camera.h:251-256) and normalised first otherwise (the constructors). */
+typedef struct PtCamera {
+    double origin[3];
+    double target[3];
+    double up[3];
+    double fov_deg;
+    double aspect_ratio;
+    double aperture;
+    double focus_dist;
+    uint32_t width;
+    uint32_t height;
+    uint32_t use_dof;      /* carried for shape; the render loops never use DOF */
+    uint32_t model;        /* PT_CAMERA_CUDA | PT_CAMERA_CPU */
+    uint32_t normalize_up; /* 1 = constructor behaviour */
+} PtCamera;
+
+/* ---------------------------------------------------------------- render -- */
+#define PT_INTEGRATOR_PATH 0u   /* traceRay, raytracer_kernel.cu:202-243 (FP32)   */
+#define PT_INTEGRATOR_DIRECT 1u /* renderRegion, cpu_pathtracer/src/main.cpp:14-53 (FP64) */
+
+#define PT_FLAG_NEE_MIS 1u      /* next-event estimation + balance-heuristic MIS (north_star addition) */
+#define PT_FLAG_LIGHT_COLOUR 2u /* lights emit their makeEmissive colour*strength instead of the shared
+                                   Emissive material's (reference behaviour) */
+#define PT_FLAG_COUNTERS 4u     /* count rays / bounces for pt_counters (instrumented kernel) */
+
+#define PT_ACC_SUM 0u          /* buffer holds (sum_r, sum_g, sum_b, n_samples) */
+#define PT_ACC_RUNNING_MEAN 1u /* renderKernel's in-place mean, alpha = 1 (raytracer_kernel.cu:297-304) */
+
+typedef struct PtRenderParams {
+    uint32_t integrator;    /* PT_INTEGRATOR_*                                         */
+    uint32_t max_depth;     /* 50 in the reference (raytracer_kernel.cu:294)           */
+    uint32_t rr_depth;      /* Russian roulette when depth > rr_depth; reference: 3    */
+    uint32_t seed;          /* counter-RNG seed (replaces curand_init, :267-272)       */
+    uint32_t flags;         /* PT_FLAG_*                                               */
+    uint32_t acc_mode;      /* PT_ACC_*                                                */
+    uint32_t fused_rgba8;   /* != 0: the render launch also writes the display buffer
+                               (convertToRGBAKernel, Window.cuh:16-30) for the pixels it touched */
+    uint32_t pixels_per_wave; /* tuning knob, 0 = library default                      */
+} PtRenderParams;
+
+/* Event counts of the instrumented kernel; identical on CPU oracle and GPU
+ * because both key the RNG on (pixel, sample, bounce).  Feed the fixed FLOP
+ * table of SURVEY §8(d). */
+typedef struct PtCounters {
+    uint64_t samples;         /* camera paths started                                  */
+    uint64_t rays;            /* intersectScene calls, shadow rays included            */
+    uint64_t hits;            /* rays that hit something (winning-hit records built)   */
+    uint64_t sphere_roots;    /* ray-sphere tests with discriminant >= 0               */
+    uint64_t bounces[5];      /* scatter evaluations per PT_MAT_* of the hit material  */
+    uint64_t diffuse_updates; /* non-specular throughput/RR updates (:229-238)         */
+    uint64_t nee_samples;     /* light samples drawn (PT_FLAG_NEE_MIS)                 */
+    uint64_t shadow_rays;     /* of `rays`, how many were shadow rays                  */
+} PtCounters;
+
+#define PT_RESOLVE_RGBA8_CUDA 0u /* clamp(c*255,0,255) truncated, 0x00RRGGBB (Window.cuh:25-29)         */
+#define PT_RESOLVE_RGBA8_CPU 1u  /* clamp, pow(1/2.2), *255 truncated, 0x00RRGGBB
+                                    (main.cpp:228-236 + WindowX11.h:130-139)                            */
+#define PT_RESOLVE_FLOAT_MEAN 2u /* float4 (mean_r, mean_g, mean_b, 1)                                   */
+#define PT_RESOLVE_RGB8_PPM 3u   /* 3 bytes/pixel, gamma 2.2, +0.5 rounding (Camera.h:162-180, Color.h:86-91) */
+
+typedef struct PtContext PtContext;
+
+/* -- lifetime ------------------------------------------------------------- */
+/* Replaces initializeCuda()/cudaSetDevice(0) (main.cu:28-40). */
+int pt_create(int device_id, PtContext** out_ctx);
+int pt_destroy(PtContext* ctx);
+const char* pt_last_error(void);
+/* Library/ABI version, for the binding to check. */
+uint32_t pt_abi_version(void);
+
+/* Use an existing HIP stream (e.g. torch's current stream) for all work of the
+ * context; NULL restores the context's own stream. */
+int pt_set_stream(PtContext* ctx, void* hip_stream);
+
+/* -- scene / camera -------------------------------------------------------- */
+/* Replaces MaterialFactory::createMaterialsOnDevice (MaterialFactory.cuh:41-75),
+ * the flatten loop and the cudaMemcpyToSymbol uploads (main.cu:214-278). */
+int pt_upload_scene(PtContext* ctx, const PtSceneSoA* scene);
+/* Replaces initializeGPUData(camera, scene) (raytracer_kernel.cu:308-321). Also
+ * sets the frame size to camera->width x camera->height (allocating the
+ * accumulation and display buffers unless one is bound). */
+int pt_set_camera(PtContext* ctx, const PtCamera* camera);
+/* Replaces the cudaMalloc of d_output (main.cu:55-57) / Window_t's RGBA buffer. */
+int pt_resize(PtContext* ctx, uint32_t width, uint32_t height);
+/* Render into a caller-owned device buffer of width*height float4 instead of
+ * the context's own (NULL unbinds).  This is how a torch tensor becomes the
+ * accumulation buffer for the RCCL reduce. */
+int pt_bind_accum(PtContext* ctx, void* dev_float4);
+/* Zero the accumulation buffer and the sample count — the CPU app's reset on
+ * camera movement (cpu_pathtracer/src/main.cpp:201-205). */
+int pt_reset(PtContext* ctx);
+
+/* -- render ---------------------------------------------------------------- */
+/* Adds samples [sample_begin, sample_begin+sample_count) to every pixel;
+ * generalises launchRenderKernel's frame_count (one sample per launch).
+ * Asynchronous on the context's stream. */
+int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
+              const PtRenderParams* params);
+/* Resolve the accumulation buffer into the context's display buffer
+ * (convertToRGBAKernel / the CPU accumulate+gamma loop).  Asynchronous. */
+int pt_resolve(PtContext* ctx, uint32_t mode);
+/* Copy the display buffer of the last pt_resolve / fused render to the host
+ * (Window_t::updateScreen's cudaMemcpy, Window.cuh:160).  Synchronises. */
+int pt_readback(PtContext* ctx, void* host_dst, size_t bytes);
+/* Copy the raw accumulation buffer (width*height float4) to the host. Synchronises. */
+int pt_readback_accum(PtContext* ctx, float* host_dst, size_t bytes);
+/* Upload a raw accumulation buffer (resume from a checkpoint). */
+int pt_upload_accum(PtContext* ctx, const float* host_src, size_t bytes);
+int pt_sync(PtContext* ctx);
+
+/* Device pointers for callers that drive collectives themselves. */
+void* pt_accum_device_ptr(PtContext* ctx);
+void* pt_display_device_ptr(PtContext* ctx);
+
+/* -- checks / measurement --------------------------------------------------- */
+/* Primary-hit object id and material id per pixel through the pixel centre, in
+ * FP64 with the formulas of Scene::intersect (cpu_pathtracer/include/Scene.h:52-72)
+ * and the camera model set by pt_set_camera.  0xFFFFFFFF = miss.  Either output
+ * may be NULL.  Synchronises. */
+int pt_primary_ids(PtContext* ctx, uint32_t* host_obj_ids, uint32_t* host_mat_ids);
+/* Counters accumulated by renders run with PT_FLAG_COUNTERS since the last
+ * pt_reset_counters.  Synchronises. */
+int pt_counters(PtContext* ctx, PtCounters* out);
+int pt_reset_counters(PtContext* ctx);
+/* FP32 VALU ceiling micro-benchmark: runs `iters` dependent-chain FMA rounds on
+ * every lane of a full-chip grid; packed != 0 uses v_pk_fma_f32.  Returns the
+ * achieved TFLOP/s in *out_tflops.  Synchronises. */
+int pt_valu_peak(PtContext* ctx, uint32_t packed, uint32_t iters, double* out_tflops);
+
+/* -- reference call shape ---------------------------------------------------- */
+/* launchRenderKernel(float4* output, w, h, frame_count, grid, block)
+ * (raytracer_kernel.cuh:51, raytracer_kernel.cu:325-327) on the context made
+ * current by pt_make_current(): one more sample per pixel, running mean in
+ * `output` (device, caller-owned); frame_count == 0 overwrites.  grid/block are
+ * accepted as six integers and ignored (the launch shape is the library's). */
+int pt_make_current(PtContext* ctx);
+void launchRenderKernel(void* output_float4, uint32_t width, uint32_t height, uint32_t frame_count,
+                        uint32_t grid_x, uint32_t grid_y, uint32_t grid_z,
+                        uint32_t block_x, uint32_t block_y, uint32_t block_z);
+
+/* -- built-in scenes (host only, no GPU needed) ------------------------------ */
+/* Fills *scene and *camera with pointers into storage owned by the library
+ * (valid until the next call with the same name from the same thread).
+ * Names: "cpu_default" (main.cpp:63-131), "cuda_default" (main.cu:64-200),
+ * "glass_stress", "random4096" (SURVEY §8d configs 4 and 5). */
+int pt_builtin_scene(const char* name, uint32_t width, uint32_t height,
+                     PtSceneSoA* scene, PtCamera* camera);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_H_ */

@@ -1,0 +1,566 @@
+// pt_api.cpp — the C ABI of include/pt.h: contexts, scene/camera upload, render/resolve
+// launches.  Host code only (compiled by hipcc for the HIP runtime API); the kernels live in
+// pt_path_kernel.hip and pt_f64_kernels.hip.
+//
+// Replaces, on the reference side: initializeCuda / cudaMalloc of d_output (main.cu:28-57),
+// MaterialFactory::createMaterialsOnDevice (MaterialFactory.cuh:41-75), the flatten +
+// cudaMemcpyToSymbol upload (main.cu:214-278), initializeGPUData (raytracer_kernel.cu:308-321),
+// launchRenderKernel (:325-327) and Window_t::updateScreen's device half (Window.cuh:147-165).
+#include "../../include/pt.h"
+#include "pt_device.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace {
+
+thread_local std::string g_err;
+thread_local PtContext* g_current = nullptr;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(PT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace
+
+struct PtContext {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // scene
+    void* scene_arena = nullptr;
+    bool have_scene = false;
+    DevSceneF sf{};
+    DevSceneD sd{};
+    // camera / frame
+    bool have_camera = false;
+    DevCamF cf{};
+    DevCamD cd{};
+    uint32_t width = 0, height = 0;
+    float4* accum_own = nullptr;
+    float4* accum = nullptr;  // own or bound
+    bool accum_bound = false;
+    void* display = nullptr;  // 16 B / pixel: large enough for every resolve mode
+    size_t display_bytes = 0;  // bytes the last resolve produced
+    uint32_t last_acc_mode = PT_ACC_SUM;
+    uint64_t* counters = nullptr;  // 12 x u64
+    uint32_t* ids = nullptr;       // 2 * npix, allocated on demand
+    float* sink = nullptr;
+};
+
+namespace {
+
+int use(PtContext* ctx) {
+    if (!ctx) return fail(PT_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return PT_OK;
+}
+
+int alloc_frame(PtContext* ctx, uint32_t w, uint32_t h) {
+    if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) return fail(PT_ERR_INVALID, "bad frame size %ux%u", w, h);
+    if (w == ctx->width && h == ctx->height && ctx->display) return PT_OK;
+    const size_t npix = (size_t)w * h;
+    if (ctx->accum_own) { HIP_TRY(hipFree(ctx->accum_own)); ctx->accum_own = nullptr; }
+    if (ctx->display) { HIP_TRY(hipFree(ctx->display)); ctx->display = nullptr; }
+    if (ctx->ids) { HIP_TRY(hipFree(ctx->ids)); ctx->ids = nullptr; }
+    HIP_TRY(hipMalloc((void**)&ctx->accum_own, npix * sizeof(float4)));
+    HIP_TRY(hipMalloc(&ctx->display, npix * 16));
+    HIP_TRY(hipMemsetAsync(ctx->accum_own, 0, npix * sizeof(float4), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->display, 0, npix * 16, ctx->stream));
+    ctx->width = w;
+    ctx->height = h;
+    ctx->display_bytes = 0;
+    if (ctx->accum_bound) {  // a bound buffer was sized for the old frame
+        ctx->accum_bound = false;
+    }
+    ctx->accum = ctx->accum_own;
+    return PT_OK;
+}
+
+struct F3 { float x, y, z; };
+inline F3 fnorm(F3 a) {  // Vec3.cuh:49-61, float
+    float l = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    if (l > 0) { float il = 1 / l; a.x *= il; a.y *= il; a.z *= il; }
+    return a;
+}
+inline F3 fcross(F3 u, F3 v) { return F3{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x}; }
+
+struct D3h { double x, y, z; };
+inline D3h dnorm(D3h a) {  // Vec3.h:48-63
+    double l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    if (l > 0) { double il = 1 / l; a.x *= il; a.y *= il; a.z *= il; }
+    return a;
+}
+inline D3h dcross(D3h u, D3h v) { return D3h{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x}; }
+inline D3h dmul(D3h a, double t) { return D3h{a.x * t, a.y * t, a.z * t}; }
+inline D3h dadd(D3h a, D3h b) { return D3h{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline D3h dsub(D3h a, D3h b) { return D3h{a.x - b.x, a.y - b.y, a.z - b.z}; }
+
+inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+}  // namespace
+
+extern "C" {
+
+const char* pt_last_error(void) { return g_err.c_str(); }
+uint32_t pt_abi_version(void) { return 1u; }
+
+int pt_create(int device_id, PtContext** out) {
+    if (!out) return fail(PT_ERR_INVALID, "out_ctx is null");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return fail(PT_ERR_INVALID, "device %d out of range (%d devices)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    PtContext* ctx = new (std::nothrow) PtContext();
+    if (!ctx) return fail(PT_ERR_INVALID, "out of host memory");
+    ctx->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail(PT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    ctx->stream = ctx->own_stream;
+    e = hipMalloc((void**)&ctx->counters, 12 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemset(ctx->counters, 0, 12 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->sink, 256);
+    if (e != hipSuccess) { pt_destroy(ctx); return fail(PT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e)); }
+    *out = ctx;
+    return PT_OK;
+}
+
+int pt_destroy(PtContext* ctx) {
+    if (!ctx) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); }
+    if (ctx->scene_arena) (void)hipFree(ctx->scene_arena);
+    if (ctx->accum_own) (void)hipFree(ctx->accum_own);
+    if (ctx->display) (void)hipFree(ctx->display);
+    if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->ids) (void)hipFree(ctx->ids);
+    if (ctx->sink) (void)hipFree(ctx->sink);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (g_current == ctx) g_current = nullptr;
+    delete ctx;
+    return PT_OK;
+}
+
+int pt_set_stream(PtContext* ctx, void* hip_stream) {
+    if (int rc = use(ctx)) return rc;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return PT_OK;
+}
+
+int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
+    if (int rc = use(ctx)) return rc;
+    if (!s) return fail(PT_ERR_INVALID, "scene is null");
+    const uint32_t ns = s->num_spheres, np = s->num_planes, nt = s->num_triangles, nm = s->num_materials;
+    if (ns > PT_MAX_SPHERES || np > PT_MAX_PLANES || nt > PT_MAX_TRIANGLES || nm > PT_MAX_MATERIALS)
+        return fail(PT_ERR_CAPACITY, "scene exceeds capacity (%u spheres / %u planes / %u triangles / %u materials)", ns, np, nt, nm);
+    if (nm == 0 || ns + np + nt == 0) return fail(PT_ERR_INVALID, "scene needs at least one primitive and one material");
+#define NEED(cnt, ptr) if ((cnt) && !(s->ptr)) return fail(PT_ERR_INVALID, "scene array " #ptr " is null")
+    NEED(ns, sph_cx); NEED(ns, sph_cy); NEED(ns, sph_cz); NEED(ns, sph_r); NEED(ns, sph_mat); NEED(ns, sph_obj);
+    NEED(ns, sph_emissive); NEED(ns, sph_em_r); NEED(ns, sph_em_g); NEED(ns, sph_em_b);
+    NEED(np, pl_px); NEED(np, pl_py); NEED(np, pl_pz); NEED(np, pl_nx); NEED(np, pl_ny); NEED(np, pl_nz); NEED(np, pl_mat); NEED(np, pl_obj);
+    NEED(nt, tri_v0x); NEED(nt, tri_v0y); NEED(nt, tri_v0z); NEED(nt, tri_v1x); NEED(nt, tri_v1y); NEED(nt, tri_v1z);
+    NEED(nt, tri_v2x); NEED(nt, tri_v2y); NEED(nt, tri_v2z); NEED(nt, tri_mat); NEED(nt, tri_obj);
+    NEED(nm, mat_type); NEED(nm, mat_albedo_r); NEED(nm, mat_albedo_g); NEED(nm, mat_albedo_b); NEED(nm, mat_roughness);
+    NEED(nm, mat_metallic); NEED(nm, mat_ior); NEED(nm, mat_em_r); NEED(nm, mat_em_g); NEED(nm, mat_em_b);
+#undef NEED
+    for (uint32_t i = 0; i < nm; ++i)
+        if (s->mat_type[i] > PT_MAT_EMISSIVE) return fail(PT_ERR_INVALID, "material %u has unknown type %u", i, s->mat_type[i]);
+    for (uint32_t i = 0; i < ns; ++i) {
+        if (s->sph_mat[i] >= nm) return fail(PT_ERR_INVALID, "sphere %u: material index %u out of range", i, s->sph_mat[i]);
+        if (!(s->sph_r[i] > 0)) return fail(PT_ERR_INVALID, "sphere %u: radius must be positive", i);
+    }
+    for (uint32_t i = 0; i < np; ++i)
+        if (s->pl_mat[i] >= nm) return fail(PT_ERR_INVALID, "plane %u: material index %u out of range", i, s->pl_mat[i]);
+    for (uint32_t i = 0; i < nt; ++i)
+        if (s->tri_mat[i] >= nm) return fail(PT_ERR_INVALID, "triangle %u: material index %u out of range", i, s->tri_mat[i]);
+
+    // ---- light list: spheres whose material is Emissive, in sphere order
+    std::vector<int32_t> sphere_light(ns, -1);
+    std::vector<uint32_t> light_sphere;
+    for (uint32_t i = 0; i < ns; ++i)
+        if (s->mat_type[s->sph_mat[i]] == PT_MAT_EMISSIVE) { sphere_light[i] = (int32_t)light_sphere.size(); light_sphere.push_back(i); }
+    const uint32_t nl = (uint32_t)light_sphere.size();
+
+    // ---- host staging, one arena: [float4 arrays][u32 arrays][double arrays]
+    std::vector<float4> f4;
+    auto push4 = [&](float x, float y, float z, float w) { f4.push_back(make_float4(x, y, z, w)); };
+    const size_t o_sph = f4.size();
+    for (uint32_t i = 0; i < ns; ++i) { float r = (float)s->sph_r[i]; push4((float)s->sph_cx[i], (float)s->sph_cy[i], (float)s->sph_cz[i], r * r); }
+    const size_t o_aux = f4.size();
+    for (uint32_t i = 0; i < ns; ++i) {
+        float r = (float)s->sph_r[i];
+        push4(1.0f / r, u2f(s->sph_mat[i]), u2f((uint32_t)sphere_light[i]), u2f(s->sph_emissive[i] ? 1u : 0u));
+    }
+    const size_t o_sem = f4.size();
+    for (uint32_t i = 0; i < ns; ++i) push4((float)s->sph_em_r[i], (float)s->sph_em_g[i], (float)s->sph_em_b[i], 0.f);
+    const size_t o_plp = f4.size();
+    for (uint32_t i = 0; i < np; ++i) push4((float)s->pl_px[i], (float)s->pl_py[i], (float)s->pl_pz[i], 0.f);
+    const size_t o_pln = f4.size();
+    for (uint32_t i = 0; i < np; ++i) {  // Plane_t's constructor normalises in float (ImplicitObject.cuh:165)
+        F3 n = fnorm(F3{(float)s->pl_nx[i], (float)s->pl_ny[i], (float)s->pl_nz[i]});
+        push4(n.x, n.y, n.z, u2f(s->pl_mat[i]));
+    }
+    const size_t o_tri = f4.size();
+    for (uint32_t i = 0; i < nt; ++i) {
+        F3 v0{(float)s->tri_v0x[i], (float)s->tri_v0y[i], (float)s->tri_v0z[i]};
+        F3 v1{(float)s->tri_v1x[i], (float)s->tri_v1y[i], (float)s->tri_v1z[i]};
+        F3 v2{(float)s->tri_v2x[i], (float)s->tri_v2y[i], (float)s->tri_v2z[i]};
+        F3 e1{v1.x - v0.x, v1.y - v0.y, v1.z - v0.z}, e2{v2.x - v0.x, v2.y - v0.y, v2.z - v0.z};
+        F3 n = fnorm(fcross(e1, e2));  // Triangle_t::computeNormal, Polygon.cuh:53-57
+        push4(v0.x, v0.y, v0.z, 0.f); push4(e1.x, e1.y, e1.z, 0.f); push4(e2.x, e2.y, e2.z, 0.f);
+        push4(n.x, n.y, n.z, u2f(s->tri_mat[i]));
+    }
+    const size_t o_ma = f4.size();
+    for (uint32_t i = 0; i < nm; ++i) push4((float)s->mat_albedo_r[i], (float)s->mat_albedo_g[i], (float)s->mat_albedo_b[i], u2f(s->mat_type[i]));
+    const size_t o_mb = f4.size();
+    for (uint32_t i = 0; i < nm; ++i) {
+        float rough = (float)s->mat_roughness[i];
+        if (s->mat_type[i] == PT_MAT_METAL) rough = rough < 1.0f ? rough : 1.0f;  // Metal_t ctor, Material.cuh:94
+        push4(rough, (float)s->mat_metallic[i], (float)s->mat_ior[i], 0.f);
+    }
+    const size_t o_me = f4.size();
+    for (uint32_t i = 0; i < nm; ++i) push4((float)s->mat_em_r[i], (float)s->mat_em_g[i], (float)s->mat_em_b[i], 0.f);
+    const size_t o_lt = f4.size();
+    for (uint32_t j = 0; j < nl; ++j) f4.push_back(f4[o_sph + light_sphere[j]]);
+    if (nl == 0) push4(0, 0, 0, 0);
+
+    std::vector<uint32_t> u32;
+    const size_t o_ls = u32.size();
+    for (uint32_t j = 0; j < nl; ++j) u32.push_back(light_sphere[j]);
+    if (nl == 0) u32.push_back(0);
+    const size_t o_obj = u32.size();
+    for (uint32_t i = 0; i < ns; ++i) u32.push_back(s->sph_obj[i]);
+    for (uint32_t i = 0; i < np; ++i) u32.push_back(s->pl_obj[i]);
+    for (uint32_t i = 0; i < nt; ++i) u32.push_back(s->tri_obj[i]);
+    const size_t o_si = u32.size();
+    for (uint32_t i = 0; i < ns; ++i) { u32.push_back(s->sph_mat[i]); u32.push_back(s->sph_obj[i]); u32.push_back(s->sph_emissive[i] ? 1u : 0u); }
+    const size_t o_pi = u32.size();
+    for (uint32_t i = 0; i < np; ++i) { u32.push_back(s->pl_mat[i]); u32.push_back(s->pl_obj[i]); }
+    const size_t o_ti = u32.size();
+    for (uint32_t i = 0; i < nt; ++i) { u32.push_back(s->tri_mat[i]); u32.push_back(s->tri_obj[i]); }
+    while (u32.size() % 4) u32.push_back(0);
+
+    std::vector<double> f8;
+    const size_t o_dsph = f8.size();
+    for (uint32_t i = 0; i < ns; ++i) { f8.push_back(s->sph_cx[i]); f8.push_back(s->sph_cy[i]); f8.push_back(s->sph_cz[i]); f8.push_back(s->sph_r[i]); }
+    const size_t o_dpl = f8.size();
+    for (uint32_t i = 0; i < np; ++i) {  // Plane's constructor normalises in double (ImplicitObject.h:143)
+        D3h n = dnorm(D3h{s->pl_nx[i], s->pl_ny[i], s->pl_nz[i]});
+        f8.push_back(s->pl_px[i]); f8.push_back(s->pl_py[i]); f8.push_back(s->pl_pz[i]);
+        f8.push_back(n.x); f8.push_back(n.y); f8.push_back(n.z);
+    }
+    const size_t o_dtri = f8.size();
+    for (uint32_t i = 0; i < nt; ++i) {
+        f8.push_back(s->tri_v0x[i]); f8.push_back(s->tri_v0y[i]); f8.push_back(s->tri_v0z[i]);
+        f8.push_back(s->tri_v1x[i]); f8.push_back(s->tri_v1y[i]); f8.push_back(s->tri_v1z[i]);
+        f8.push_back(s->tri_v2x[i]); f8.push_back(s->tri_v2y[i]); f8.push_back(s->tri_v2z[i]);
+    }
+    const size_t o_dem = f8.size();
+    for (uint32_t i = 0; i < ns; ++i) { f8.push_back(s->sph_em_r[i]); f8.push_back(s->sph_em_g[i]); f8.push_back(s->sph_em_b[i]); }
+    const size_t o_dal = f8.size();
+    for (uint32_t i = 0; i < nm; ++i) { f8.push_back(s->mat_albedo_r[i]); f8.push_back(s->mat_albedo_g[i]); f8.push_back(s->mat_albedo_b[i]); }
+    f8.push_back(0.0);
+
+    const size_t b_f4 = f4.size() * sizeof(float4), b_u32 = u32.size() * 4, b_f8 = f8.size() * 8;
+    const size_t total = b_f4 + b_u32 + b_f8;
+    std::vector<unsigned char> host(total);
+    memcpy(host.data(), f4.data(), b_f4);
+    memcpy(host.data() + b_f4, u32.data(), b_u32);
+    memcpy(host.data() + b_f4 + b_u32, f8.data(), b_f8);
+
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // no launch may still read the old scene
+    if (ctx->scene_arena) { HIP_TRY(hipFree(ctx->scene_arena)); ctx->scene_arena = nullptr; ctx->have_scene = false; }
+    HIP_TRY(hipMalloc(&ctx->scene_arena, total));
+    HIP_TRY(hipMemcpy(ctx->scene_arena, host.data(), total, hipMemcpyHostToDevice));
+
+    const float4* F = (const float4*)ctx->scene_arena;
+    const uint32_t* U = (const uint32_t*)((const unsigned char*)ctx->scene_arena + b_f4);
+    const double* D = (const double*)((const unsigned char*)ctx->scene_arena + b_f4 + b_u32);
+    DevSceneF& sf = ctx->sf;
+    sf.sph = F + o_sph; sf.sph_aux = F + o_aux; sf.sph_em = F + o_sem; sf.pl_p = F + o_plp; sf.pl_n = F + o_pln;
+    sf.tri = F + o_tri; sf.mat_a = F + o_ma; sf.mat_b = F + o_mb; sf.mat_e = F + o_me; sf.lights = F + o_lt;
+    sf.light_sphere = U + o_ls; sf.obj_ids = U + o_obj;
+    sf.ns = (int)ns; sf.np = (int)np; sf.nt = (int)nt; sf.nl = (int)nl;
+    DevSceneD& sd = ctx->sd;
+    sd.sph = D + o_dsph; sd.pl = D + o_dpl; sd.tri = D + o_dtri; sd.sph_em = D + o_dem; sd.mat_albedo = D + o_dal;
+    sd.sph_info = U + o_si; sd.pl_info = U + o_pi; sd.tri_info = U + o_ti;
+    sd.ns = (int)ns; sd.np = (int)np; sd.nt = (int)nt;
+    ctx->have_scene = true;
+    return PT_OK;
+}
+
+int pt_resize(PtContext* ctx, uint32_t width, uint32_t height) {
+    if (int rc = use(ctx)) return rc;
+    return alloc_frame(ctx, width, height);
+}
+
+int pt_set_camera(PtContext* ctx, const PtCamera* c) {
+    if (int rc = use(ctx)) return rc;
+    if (!c) return fail(PT_ERR_INVALID, "camera is null");
+    if (c->model > PT_CAMERA_CPU) return fail(PT_ERR_INVALID, "unknown camera model %u", c->model);
+    if (c->width == 0 || c->height == 0) return fail(PT_ERR_INVALID, "camera has zero width or height");
+    if (c->model == PT_CAMERA_CPU && (c->width < 2 || c->height < 2))
+        return fail(PT_ERR_INVALID, "the CPU camera divides by (width-1) and (height-1)");
+    if (!(c->fov_deg > 0.0 && c->fov_deg < 180.0)) return fail(PT_ERR_INVALID, "fov must be in (0,180) degrees");
+    if (int rc = alloc_frame(ctx, c->width, c->height)) return rc;
+
+    // ---- Camera_t::initialize (Camera.cu:3-23), float; initializeGPUData (raytracer_kernel.cu:308-321)
+    F3 o{(float)c->origin[0], (float)c->origin[1], (float)c->origin[2]};
+    F3 tg{(float)c->target[0], (float)c->target[1], (float)c->target[2]};
+    F3 up{(float)c->up[0], (float)c->up[1], (float)c->up[2]};
+    if (c->normalize_up) up = fnorm(up);
+    F3 w = fnorm(F3{o.x - tg.x, o.y - tg.y, o.z - tg.z});
+    F3 u = fnorm(fcross(up, w));
+    F3 v = fcross(w, u);
+    const float fov = (float)((double)(float)c->fov_deg * M_PI / 180.0f);  // :315
+    const float aspect = (float)c->width / (float)(int)c->height;           // :247
+    const float vh = 2.0f * tanf(fov * 0.5f);                               // :248
+    const float vw = aspect * vh;
+    DevCamF& cf = ctx->cf;
+    cf.ox = o.x; cf.oy = o.y; cf.oz = o.z;
+    cf.fx = -w.x; cf.fy = -w.y; cf.fz = -w.z;
+    cf.rx = u.x; cf.ry = u.y; cf.rz = u.z;
+    cf.ux = v.x; cf.uy = v.y; cf.uz = v.z;
+    cf.half_w = vw * 0.5f; cf.half_h = vh * 0.5f;
+    cf.width = c->width; cf.height = c->height;
+
+    DevCamD& cd = ctx->cd;
+    memset(&cd, 0, sizeof cd);
+    cd.model = c->model; cd.width = c->width; cd.height = c->height;
+    if (c->model == PT_CAMERA_CPU) {
+        // ---- Camera::initialize, cpu_pathtracer/include/Camera.h:65-85, double
+        D3h od{c->origin[0], c->origin[1], c->origin[2]}, td{c->target[0], c->target[1], c->target[2]};
+        D3h ud{c->up[0], c->up[1], c->up[2]};
+        if (c->normalize_up) ud = dnorm(ud);
+        D3h wd = dnorm(dsub(od, td));
+        D3h uu = dnorm(dcross(ud, wd));
+        D3h vv = dcross(wd, uu);
+        const double theta = c->fov_deg * M_PI / 180.0;
+        const double vhd = 2.0 * std::tan(theta / 2.0);
+        const double vwd = vhd * c->aspect_ratio;
+        D3h hor = dmul(dmul(uu, vwd), c->focus_dist), ver = dmul(dmul(vv, vhd), c->focus_dist);
+        D3h tl = dsub(dadd(dsub(od, dmul(hor, 1 / 2.0)), dmul(ver, 1 / 2.0)), dmul(wd, c->focus_dist));
+        cd.origin[0] = od.x; cd.origin[1] = od.y; cd.origin[2] = od.z;
+        cd.top_left[0] = tl.x; cd.top_left[1] = tl.y; cd.top_left[2] = tl.z;
+        cd.horizontal[0] = hor.x; cd.horizontal[1] = hor.y; cd.horizontal[2] = hor.z;
+        cd.vertical[0] = ver.x; cd.vertical[1] = ver.y; cd.vertical[2] = ver.z;
+    } else {
+        cd.origin[0] = o.x; cd.origin[1] = o.y; cd.origin[2] = o.z;
+        cd.fwd[0] = -w.x; cd.fwd[1] = -w.y; cd.fwd[2] = -w.z;
+        cd.right[0] = u.x; cd.right[1] = u.y; cd.right[2] = u.z;
+        cd.up[0] = v.x; cd.up[1] = v.y; cd.up[2] = v.z;
+        const double aspd = (double)(float)c->width / (double)(int)c->height;
+        const double vhd = 2.0 * std::tan((double)fov * 0.5);
+        const double vwd = aspd * vhd;
+        cd.half_w = vwd * 0.5; cd.half_h = vhd * 0.5;
+    }
+    ctx->have_camera = true;
+    return PT_OK;
+}
+
+int pt_bind_accum(PtContext* ctx, void* dev_float4) {
+    if (int rc = use(ctx)) return rc;
+    if (ctx->width == 0) return fail(PT_ERR_STATE, "set the frame size (pt_set_camera / pt_resize) before binding a buffer");
+    if (dev_float4) {
+        if (((uintptr_t)dev_float4 & 15u) != 0) return fail(PT_ERR_INVALID, "accumulation buffer must be 16-byte aligned");
+        ctx->accum = (float4*)dev_float4; ctx->accum_bound = true;
+    } else {
+        ctx->accum = ctx->accum_own; ctx->accum_bound = false;
+    }
+    return PT_OK;
+}
+
+int pt_reset(PtContext* ctx) {
+    if (int rc = use(ctx)) return rc;
+    if (!ctx->accum) return fail(PT_ERR_STATE, "no frame allocated");
+    HIP_TRY(hipMemsetAsync(ctx->accum, 0, (size_t)ctx->width * ctx->height * sizeof(float4), ctx->stream));
+    return PT_OK;
+}
+
+int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm) {
+    if (int rc = use(ctx)) return rc;
+    if (!prm) return fail(PT_ERR_INVALID, "params is null");
+    if (!ctx->have_scene) return fail(PT_ERR_STATE, "no scene uploaded");
+    if (!ctx->have_camera) return fail(PT_ERR_STATE, "no camera set");
+    if (ctx->cf.width != ctx->width || ctx->cf.height != ctx->height)
+        return fail(PT_ERR_STATE, "frame was resized to %ux%u after the camera was set for %ux%u", ctx->width, ctx->height, ctx->cf.width, ctx->cf.height);
+    if (sample_count == 0) return PT_OK;
+    if ((uint64_t)sample_begin + sample_count > 0xFFFFFFFFull) return fail(PT_ERR_INVALID, "sample range overflows 32 bits");
+    if (prm->acc_mode > PT_ACC_RUNNING_MEAN) return fail(PT_ERR_INVALID, "unknown acc_mode %u", prm->acc_mode);
+    if (prm->integrator == PT_INTEGRATOR_DIRECT) {
+        if (prm->acc_mode != PT_ACC_SUM) return fail(PT_ERR_INVALID, "the direct integrator accumulates sums only");
+        HIP_TRY(pt_launch_direct(ctx->sd, ctx->cd, ctx->accum, sample_begin, sample_count, prm->seed, ctx->stream));
+        ctx->last_acc_mode = PT_ACC_SUM;
+        return PT_OK;
+    }
+    if (prm->integrator != PT_INTEGRATOR_PATH) return fail(PT_ERR_INVALID, "unknown integrator %u", prm->integrator);
+    if (ctx->cd.model != PT_CAMERA_CUDA) return fail(PT_ERR_INVALID, "the path integrator uses the CUDA camera model");
+    if (prm->max_depth == 0) return fail(PT_ERR_INVALID, "max_depth must be at least 1");
+    if (prm->acc_mode == PT_ACC_RUNNING_MEAN && sample_count != 1)
+        return fail(PT_ERR_INVALID, "the running-mean mode adds one sample per launch, like renderKernel");
+    PathArgs a{};
+    a.accum = ctx->accum;
+    a.rgba = prm->fused_rgba8 ? (uint32_t*)ctx->display : nullptr;
+    a.counters = (prm->flags & PT_FLAG_COUNTERS) ? ctx->counters : nullptr;
+    a.s0 = sample_begin; a.count = sample_count;
+    a.max_depth = prm->max_depth; a.rr_depth = prm->rr_depth; a.seed = prm->seed;
+    a.light_colour = (prm->flags & PT_FLAG_LIGHT_COLOUR) ? 1u : 0u;
+    a.acc_mode = prm->acc_mode;
+    a.mean_t = 1.0f / (float)(sample_begin + 1u);  // :299
+    a.tiles_x = (ctx->width + 7u) / 8u; a.tiles_y = (ctx->height + 7u) / 8u;
+    a.num_tiles = a.tiles_x * a.tiles_y;
+    uint32_t tpw;
+    if (prm->pixels_per_wave) tpw = (prm->pixels_per_wave + 63u) / 64u;
+    else tpw = (a.num_tiles + 8191u) / 8192u;  // about one resident wave per slot: 256 CUs x 4 SIMDs x 8
+    a.tiles_per_wave = tpw < 1u ? 1u : (tpw > 1024u ? 1024u : tpw);
+    HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, (prm->flags & PT_FLAG_NEE_MIS) != 0, (prm->flags & PT_FLAG_COUNTERS) != 0, ctx->stream));
+    ctx->last_acc_mode = prm->acc_mode;
+    if (prm->fused_rgba8) ctx->display_bytes = (size_t)ctx->width * ctx->height * 4;
+    return PT_OK;
+}
+
+int pt_resolve(PtContext* ctx, uint32_t mode) {
+    if (int rc = use(ctx)) return rc;
+    if (!ctx->accum) return fail(PT_ERR_STATE, "no frame allocated");
+    if (mode > PT_RESOLVE_RGB8_PPM) return fail(PT_ERR_INVALID, "unknown resolve mode %u", mode);
+    const uint32_t npix = ctx->width * ctx->height;
+    HIP_TRY(pt_launch_resolve(ctx->accum, ctx->display, npix, ctx->last_acc_mode, mode, ctx->stream));
+    ctx->display_bytes = (size_t)npix * (mode == PT_RESOLVE_FLOAT_MEAN ? 16 : mode == PT_RESOLVE_RGB8_PPM ? 3 : 4);
+    return PT_OK;
+}
+
+int pt_readback(PtContext* ctx, void* host_dst, size_t bytes) {
+    if (int rc = use(ctx)) return rc;
+    if (!host_dst) return fail(PT_ERR_INVALID, "host_dst is null");
+    if (ctx->display_bytes == 0) return fail(PT_ERR_STATE, "nothing resolved yet");
+    if (bytes > ctx->display_bytes) return fail(PT_ERR_INVALID, "asked for %zu bytes, display buffer holds %zu", bytes, ctx->display_bytes);
+    HIP_TRY(hipMemcpyAsync(host_dst, ctx->display, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_readback_accum(PtContext* ctx, float* host_dst, size_t bytes) {
+    if (int rc = use(ctx)) return rc;
+    if (!host_dst) return fail(PT_ERR_INVALID, "host_dst is null");
+    if (!ctx->accum) return fail(PT_ERR_STATE, "no frame allocated");
+    const size_t have = (size_t)ctx->width * ctx->height * sizeof(float4);
+    if (bytes > have) return fail(PT_ERR_INVALID, "asked for %zu bytes, accumulation buffer holds %zu", bytes, have);
+    HIP_TRY(hipMemcpyAsync(host_dst, ctx->accum, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_upload_accum(PtContext* ctx, const float* host_src, size_t bytes) {
+    if (int rc = use(ctx)) return rc;
+    if (!host_src) return fail(PT_ERR_INVALID, "host_src is null");
+    if (!ctx->accum) return fail(PT_ERR_STATE, "no frame allocated");
+    const size_t have = (size_t)ctx->width * ctx->height * sizeof(float4);
+    if (bytes != have) return fail(PT_ERR_INVALID, "checkpoint is %zu bytes, accumulation buffer is %zu", bytes, have);
+    HIP_TRY(hipMemcpyAsync(ctx->accum, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_sync(PtContext* ctx) {
+    if (int rc = use(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+void* pt_accum_device_ptr(PtContext* ctx) { return ctx ? (void*)ctx->accum : nullptr; }
+void* pt_display_device_ptr(PtContext* ctx) { return ctx ? ctx->display : nullptr; }
+
+int pt_primary_ids(PtContext* ctx, uint32_t* host_obj, uint32_t* host_mat) {
+    if (int rc = use(ctx)) return rc;
+    if (!ctx->have_scene) return fail(PT_ERR_STATE, "no scene uploaded");
+    if (!ctx->have_camera) return fail(PT_ERR_STATE, "no camera set");
+    const size_t npix = (size_t)ctx->width * ctx->height;
+    if (!ctx->ids) HIP_TRY(hipMalloc((void**)&ctx->ids, 2 * npix * sizeof(uint32_t)));
+    HIP_TRY(pt_launch_primary_ids(ctx->sd, ctx->cd, ctx->ids, ctx->ids + npix, ctx->stream));
+    if (host_obj) HIP_TRY(hipMemcpyAsync(host_obj, ctx->ids, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (host_mat) HIP_TRY(hipMemcpyAsync(host_mat, ctx->ids + npix, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_counters(PtContext* ctx, PtCounters* out) {
+    if (int rc = use(ctx)) return rc;
+    if (!out) return fail(PT_ERR_INVALID, "out is null");
+    static_assert(sizeof(PtCounters) == 12 * sizeof(uint64_t), "PtCounters is 12 u64 in kernel order");
+    HIP_TRY(hipMemcpyAsync(out, ctx->counters, sizeof(PtCounters), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_reset_counters(PtContext* ctx) {
+    if (int rc = use(ctx)) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->counters, 0, 12 * sizeof(uint64_t), ctx->stream));
+    return PT_OK;
+}
+
+int pt_valu_peak(PtContext* ctx, uint32_t packed, uint32_t iters, double* out_tflops) {
+    if (int rc = use(ctx)) return rc;
+    if (!out_tflops || iters == 0) return fail(PT_ERR_INVALID, "bad arguments");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 8u;  // 8 blocks x 4 waves = 8 waves / SIMD
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(pt_launch_valu_peak(ctx->sink, packed, iters, blocks, ctx->stream));  // warm-up
+    HIP_TRY(hipEventRecord(e0, ctx->stream));
+    HIP_TRY(pt_launch_valu_peak(ctx->sink, packed, iters, blocks, ctx->stream));
+    HIP_TRY(hipEventRecord(e1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const double flops = (double)blocks * 256.0 * (double)iters * 16.0 * 2.0;
+    *out_tflops = flops / ((double)ms * 1e-3) / 1e12;
+    return PT_OK;
+}
+
+int pt_make_current(PtContext* ctx) {
+    g_current = ctx;
+    return PT_OK;
+}
+
+void launchRenderKernel(void* output, uint32_t width, uint32_t height, uint32_t frame_count, uint32_t, uint32_t, uint32_t,
+                        uint32_t, uint32_t, uint32_t) {
+    PtContext* ctx = g_current;
+    if (!ctx) { fail(PT_ERR_STATE, "launchRenderKernel: no current context (pt_make_current)"); return; }
+    if (width != ctx->width || height != ctx->height) { fail(PT_ERR_INVALID, "launchRenderKernel: %ux%u does not match the camera's %ux%u", width, height, ctx->width, ctx->height); return; }
+    float4* saved = ctx->accum;
+    const bool saved_bound = ctx->accum_bound;
+    if (pt_bind_accum(ctx, output) != PT_OK) return;
+    PtRenderParams p{};
+    p.integrator = PT_INTEGRATOR_PATH; p.max_depth = 50; p.rr_depth = 3; p.seed = 0x5EED0001u;  // :294, :233
+    p.acc_mode = PT_ACC_RUNNING_MEAN;
+    (void)pt_render(ctx, frame_count, 1, &p);
+    ctx->accum = saved; ctx->accum_bound = saved_bound;
+}
+
+}  // extern "C"

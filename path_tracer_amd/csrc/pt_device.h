@@ -1,0 +1,84 @@
+// pt_device.h — device-side data layout shared by the C-ABI host code and the HIP kernels.
+//
+// Layout in HBM (see DESIGN.md §Data layout).  Everything the intersection loops read is
+// indexed by a wave-uniform loop counter, so hipcc turns those reads into scalar loads
+// (s_load_dwordx4 through the scalar data cache — CDNA's counterpart of __constant__ memory)
+// and the operands live in SGPRs.  Per-lane gathers (the winning primitive's normal and
+// material) are ordinary vector loads served by L1/L2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- FP32 scene for the `path` kernel -------------------------------------------------
+struct DevSceneF {
+    const float4* sph;      // [ns]  cx, cy, cz, r*r            (loop operand, scalar loads)
+    const float4* sph_aux;  // [ns]  1/r, bits(mat), bits(light index | -1), bits(makeEmissive flag)
+    const float4* sph_em;   // [ns]  makeEmissive colour*strength, 0
+    const float4* pl_p;     // [np]  point, 0                     (loop operand)
+    const float4* pl_n;     // [np]  unit normal, bits(mat)       (loop operand; .w used by winner)
+    const float4* tri;      // [4*nt] v0 | e1=v1-v0 | e2=v2-v0 | unit normal, bits(mat)
+    const float4* mat_a;    // [nm]  albedo rgb, bits(type)
+    const float4* mat_b;    // [nm]  roughness (clamped for Metal), metallic, ior, 0
+    const float4* mat_e;    // [nm]  emission rgb (colour*strength), 0
+    const float4* lights;   // [nl]  cx, cy, cz, r*r of light j
+    const uint32_t* light_sphere;  // [nl] sphere index of light j
+    const uint32_t* obj_ids;       // [ns+np+nt] insertion index of primitive (spheres, planes, tris)
+    int ns, np, nt, nl;
+};
+
+struct DevCamF {
+    float ox, oy, oz;
+    float fx, fy, fz;  // forward = -w
+    float rx, ry, rz;  // right   =  u
+    float ux, uy, uz;  // up      =  v
+    float half_w, half_h;
+    uint32_t width, height;
+};
+
+struct PathArgs {
+    float4* accum;
+    uint32_t* rgba;       // display buffer (fused resolve) or nullptr
+    uint64_t* counters;   // 12 x u64 (PtCounters order) or nullptr
+    uint32_t s0, count;   // sample range of this launch
+    uint32_t max_depth, rr_depth, seed;
+    uint32_t light_colour;      // PT_FLAG_LIGHT_COLOUR
+    uint32_t acc_mode;          // PT_ACC_*
+    float mean_t;               // 1/(s0+1) for PT_ACC_RUNNING_MEAN
+    uint32_t tiles_x, tiles_y;  // 8x8 pixel tiles
+    uint32_t tiles_per_wave;
+    uint32_t num_tiles;
+};
+
+// ---- FP64 scene for the id pass and the `direct` integrator ---------------------------
+struct DevSceneD {
+    const double* sph;   // [ns*4]  cx, cy, cz, r
+    const double* pl;    // [np*6]  px,py,pz, nx,ny,nz (unit)
+    const double* tri;   // [nt*9]  v0, v1, v2
+    const double* sph_em;     // [ns*3]
+    const double* mat_albedo; // [nm*3]
+    const uint32_t* sph_info; // [ns*3] mat, obj, emissive
+    const uint32_t* pl_info;  // [np*2] mat, obj
+    const uint32_t* tri_info; // [nt*2] mat, obj
+    int ns, np, nt;
+};
+
+struct DevCamD {
+    uint32_t model, width, height, pad;
+    double origin[3];
+    // PT_CAMERA_CPU: Camera::initialize products
+    double top_left[3], horizontal[3], vertical[3];
+    // PT_CAMERA_CUDA: float basis widened
+    double fwd[3], right[3], up[3];
+    double half_w, half_h;
+};
+
+// ---- launchers implemented in the .hip translation units ------------------------------
+hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArgs& a, bool nee, bool count,
+                          hipStream_t stream);
+hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint32_t acc_mode, uint32_t mode,
+                             hipStream_t stream);
+hipError_t pt_launch_valu_peak(float* sink, uint32_t packed, uint32_t iters, uint32_t blocks, hipStream_t stream);
+hipError_t pt_launch_primary_ids(const DevSceneD& sc, const DevCamD& cam, uint32_t* obj, uint32_t* mat,
+                                 hipStream_t stream);
+hipError_t pt_launch_direct(const DevSceneD& sc, const DevCamD& cam, float4* accum, uint32_t s0, uint32_t count,
+                            uint32_t seed, hipStream_t stream);

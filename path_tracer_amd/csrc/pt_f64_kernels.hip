@@ -1,0 +1,218 @@
+// pt_f64_kernels.hip — the FP64 side: primary-hit ids and the `direct` integrator.
+//
+// These restate cpu_pathtracer (FP64 throughout): Scene::intersect (Scene.h:52-72),
+// Sphere::intersect / Plane::intersect (ImplicitObject.h:57-95,146-172), Triangle::intersect
+// (Polygon.h:58-94), Camera::getRayForPixel (Camera.h:124-142), Scene::isVisible (Scene.h:75-94),
+// Scene::sampleLights (Scene.h:97-112), renderRegion (src/main.cpp:14-53).
+//
+// COMPILED WITH -ffp-contract=off: every +,-,*,/,sqrt is then a single IEEE-754 double
+// operation in the reference's evaluation order, so primary-hit ids are bit-exact against a
+// CPU build of the same formulas (tests/test_parity_gpu.py).  One thread = one pixel; scene
+// operands are wave-uniform scalar loads.
+#include "pt_device.h"
+
+namespace {
+
+struct D3 { double x, y, z; };
+__device__ __forceinline__ D3 d3(double x, double y, double z) { return D3{x, y, z}; }
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ D3 operator*(D3 a, double t) { return d3(a.x * t, a.y * t, a.z * t); }
+__device__ __forceinline__ D3 operator-(D3 a) { return d3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // Vec3.h:128-131
+__device__ __forceinline__ D3 cross(D3 u, D3 v) {                                                 // Vec3.h:133-140
+    return d3(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+__device__ __forceinline__ double length(D3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }  // Vec3.h:40-46
+__device__ __forceinline__ D3 normalized(D3 a) {                                                   // Vec3.h:48-63
+    const double len = length(a);
+    if (len > 0) { const double il = 1 / len; a.x *= il; a.y *= il; a.z *= il; }
+    return a;
+}
+__device__ __forceinline__ D3 ld3(const double* p) { return d3(p[0], p[1], p[2]); }
+
+struct DRay { D3 o, d; double min_t, max_t; };
+// Ray(origin, direction): normalises; min_t 1e-8, max_t 1e30 (Ray.h:43-58)
+__device__ __forceinline__ DRay make_ray(D3 o, D3 d) { return DRay{o, normalized(d), 1e-8, 1e30}; }
+__device__ __forceinline__ bool valid_t(const DRay& r, double t) { return t >= r.min_t && t <= r.max_t; }  // Ray.h:192-194
+
+struct DHit { bool hit; double t; uint32_t obj; int kind; int prim; };
+
+// Closest hit in INSERTION order with a strict '<' (Scene.h:57-69): the SoA splits objects by
+// class, so exact distance ties go to the smaller object id.
+__device__ __forceinline__ void consider(DHit& best, double t, uint32_t obj, int kind, int prim) {
+    if (!best.hit || t < best.t || (t == best.t && obj < best.obj)) best = DHit{true, t, obj, kind, prim};
+}
+
+__device__ __forceinline__ bool sphere_t(const double* s, const DRay& ray, double& root) {  // ImplicitObject.h:57-79
+    const D3 oc = ray.o - d3(s[0], s[1], s[2]);
+    const double a = 1.0;
+    const double half_b = dot(oc, ray.d);
+    const double c = dot(oc, oc) - s[3] * s[3];
+    const double disc = half_b * half_b - a * c;
+    if (disc < 0) return false;
+    const double sqrtd = sqrt(disc);
+    root = (-half_b - sqrtd) / a;
+    if (!valid_t(ray, root)) {
+        root = (-half_b + sqrtd) / a;
+        if (!valid_t(ray, root)) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ bool plane_t(const double* p, const DRay& ray, double& t) {  // ImplicitObject.h:146-158
+    const D3 n = d3(p[3], p[4], p[5]);
+    const double denom = dot(n, ray.d);
+    if (fabs(denom) < 1e-8) return false;
+    t = dot(d3(p[0], p[1], p[2]) - ray.o, n) / denom;
+    return valid_t(ray, t);
+}
+__device__ __forceinline__ bool tri_t(const double* v, const DRay& ray, double& t) {  // Polygon.h:58-94
+    const D3 v0 = ld3(v), e1 = ld3(v + 3) - v0, e2 = ld3(v + 6) - v0;
+    const D3 h = cross(ray.d, e2);
+    const double a = dot(e1, h);
+    if (fabs(a) < 1e-8) return false;
+    const double f = 1.0 / a;
+    const D3 s = ray.o - v0;
+    const double u = f * dot(s, h);
+    if (u < 0.0 || u > 1.0) return false;
+    const D3 q = cross(s, e1);
+    const double w = f * dot(ray.d, q);
+    if (w < 0.0 || u + w > 1.0) return false;
+    t = f * dot(e2, q);
+    return valid_t(ray, t);
+}
+
+__device__ DHit scene_hit(const DevSceneD& sc, const DRay& ray) {
+    DHit best{false, 0.0, 0u, 0, 0};
+    for (int i = 0; i < sc.ns; ++i) { double t; if (sphere_t(sc.sph + 4 * i, ray, t)) consider(best, t, sc.sph_info[3 * i + 1], 0, i); }
+    for (int i = 0; i < sc.np; ++i) { double t; if (plane_t(sc.pl + 6 * i, ray, t)) consider(best, t, sc.pl_info[2 * i + 1], 1, i); }
+    for (int i = 0; i < sc.nt; ++i) { double t; if (tri_t(sc.tri + 9 * i, ray, t)) consider(best, t, sc.tri_info[2 * i + 1], 2, i); }
+    return best;
+}
+
+// Camera::getRayForPixel (Camera.h:124-142, use_dof == false) or generateCameraRay in double.
+__device__ __forceinline__ DRay camera_ray(const DevCamD& k, uint32_t x, uint32_t y, double jx, double jy) {
+    const D3 origin = ld3(k.origin);
+    if (k.model == 1u) {
+        const double u = ((double)x + jx) / (double)(k.width - 1);
+        const double v = 1.0 - ((double)y + jy) / (double)(k.height - 1);
+        const D3 pixel_loc = ld3(k.top_left) + ld3(k.horizontal) * u + ld3(k.vertical) * v;
+        return make_ray(origin, normalized(pixel_loc - origin));
+    }
+    const double u = ((double)x + jx) / (double)k.width;
+    const double v = ((double)y + jy) / (double)k.height;
+    const double xo = (2.0 * u - 1.0) * k.half_w, yo = (2.0 * v - 1.0) * k.half_h;
+    return make_ray(origin, normalized(ld3(k.fwd) + ld3(k.right) * xo + ld3(k.up) * yo));
+}
+
+__global__ __launch_bounds__(256) void pt_primary_ids_kernel(const DevSceneD sc, const DevCamD cam, uint32_t* obj,
+                                                             uint32_t* mat) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= cam.width * cam.height) return;
+    const uint32_t y = p / cam.width, x = p - y * cam.width;
+    const DRay ray = camera_ray(cam, x, y, 0.5, 0.5);  // getRayForPixel(x, y, false)
+    const DHit h = scene_hit(sc, ray);
+    uint32_t m = 0xFFFFFFFFu;
+    if (h.hit) m = h.kind == 0 ? sc.sph_info[3 * h.prim] : h.kind == 1 ? sc.pl_info[2 * h.prim] : sc.tri_info[2 * h.prim];
+    if (obj) obj[p] = h.hit ? h.obj : 0xFFFFFFFFu;
+    if (mat) mat[p] = m;
+}
+
+// Counter RNG
+__device__ __forceinline__ uint32_t pt_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t pt_draw(uint32_t key, uint32_t slot, uint32_t dim) {
+    return pt_hash(key + (slot * 8u + dim + 1u) * 0x9E3779B9U);
+}
+__device__ __forceinline__ double duni(uint32_t bits) { return (double)bits * (1.0 / 4294967296.0); }  // [0,1), Random::get
+
+// Scene::isVisible, Scene.h:75-94
+__device__ bool visible(const DevSceneD& sc, D3 from, D3 to) {
+    const D3 direction = to - from;
+    const double distance = length(direction);
+    DRay sh = make_ray(from, normalized(direction));
+    sh.max_t = length(to - sh.o);  // setEndpoint, Ray.h:175-178
+    for (int i = 0; i < sc.ns; ++i) { double t; if (sphere_t(sc.sph + 4 * i, sh, t) && t < distance) return false; }
+    for (int i = 0; i < sc.np; ++i) { double t; if (plane_t(sc.pl + 6 * i, sh, t) && t < distance) return false; }
+    for (int i = 0; i < sc.nt; ++i) { double t; if (tri_t(sc.tri + 9 * i, sh, t) && t < distance) return false; }
+    return true;
+}
+
+// renderRegion, cpu_pathtracer/src/main.cpp:14-53: ambient 0.1 + (emission | one sample per
+// light * colour*cos*50/d^2), background 0.2.  One thread = one pixel, samples in a loop.
+__global__ __launch_bounds__(256) void pt_direct_kernel(const DevSceneD sc, const DevCamD cam, float4* accum, uint32_t s0,
+                                                        uint32_t count, uint32_t seed) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= cam.width * cam.height) return;
+    const uint32_t y = p / cam.width, x = p - y * cam.width;
+    double px[3] = {0, 0, 0};
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint32_t key = pt_hash(pt_hash(pt_hash(seed) + p) + (s0 + i));
+        const DRay ray = camera_ray(cam, x, y, duni(pt_draw(key, 0, 0)), duni(pt_draw(key, 0, 1)));
+        const DHit h = scene_hit(sc, ray);
+        if (!h.hit) { px[0] += 0.2; px[1] += 0.2; px[2] += 0.2; continue; }
+        px[0] += 0.1; px[1] += 0.1; px[2] += 0.1;
+        if (h.kind == 0 && sc.sph_info[3 * h.prim + 2] != 0u) {
+            px[0] += sc.sph_em[3 * h.prim]; px[1] += sc.sph_em[3 * h.prim + 1]; px[2] += sc.sph_em[3 * h.prim + 2];
+            continue;
+        }
+        // hit record of the winner
+        const D3 hp = ray.o + ray.d * h.t;
+        D3 n; uint32_t m;
+        if (h.kind == 0) {
+            const double* s = sc.sph + 4 * h.prim;
+            n = (hp - d3(s[0], s[1], s[2])) * (1 / s[3]);  // getNormalAt, ImplicitObject.h:97-99 + Vec3.h:118-121
+            m = sc.sph_info[3 * h.prim];
+        } else if (h.kind == 1) {
+            n = ld3(sc.pl + 6 * h.prim + 3); m = sc.pl_info[2 * h.prim];
+        } else {
+            const double* v = sc.tri + 9 * h.prim;
+            n = normalized(cross(ld3(v + 3) - ld3(v), ld3(v + 6) - ld3(v))); m = sc.tri_info[2 * h.prim];
+        }
+        if (!(dot(ray.d, n) < 0)) n = -n;  // setFaceNormal, Intersection.h:16-19
+        double direct[3] = {0, 0, 0};
+        uint32_t light = 0;
+        for (int l = 0; l < sc.ns; ++l) {
+            if (sc.sph_info[3 * l + 2] == 0u) continue;
+            const double u = duni(pt_draw(key, 1 + light, 0)), v = duni(pt_draw(key, 1 + light, 1));
+            light++;
+            // Sphere::getRandomPoint, ImplicitObject.h:111-125
+            const double theta = 2.0 * M_PI * u;
+            const double phi = acos(2.0 * v - 1.0);
+            const double sin_phi = sin(phi);
+            const D3 dir = d3(cos(theta) * sin_phi, sin(theta) * sin_phi, cos(phi));
+            const double* s = sc.sph + 4 * l;
+            const D3 lp = d3(s[0], s[1], s[2]) + dir * s[3];
+            const D3 light_dir = normalized(lp - hp);
+            const double cos_theta = fmax(0.0, dot(n, light_dir));
+            if (cos_theta > 0 && visible(sc, hp, lp)) {
+                const double ld = length(lp - hp);
+                const double att = 1.0 / (ld * ld);
+                for (int ch = 0; ch < 3; ++ch) direct[ch] += sc.mat_albedo[3 * m + ch] * cos_theta * att * 50.0;
+            }
+        }
+        px[0] += direct[0]; px[1] += direct[1]; px[2] += direct[2];  // pixel_color += direct_light, main.cpp:42
+    }
+    float4 a = accum[p];
+    a.x += (float)px[0]; a.y += (float)px[1]; a.z += (float)px[2]; a.w += (float)count;
+    accum[p] = a;
+}
+
+}  // namespace
+
+hipError_t pt_launch_primary_ids(const DevSceneD& sc, const DevCamD& cam, uint32_t* obj, uint32_t* mat, hipStream_t stream) {
+    const uint32_t n = cam.width * cam.height;
+    hipLaunchKernelGGL(pt_primary_ids_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, cam, obj, mat);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_direct(const DevSceneD& sc, const DevCamD& cam, float4* accum, uint32_t s0, uint32_t count,
+                            uint32_t seed, hipStream_t stream) {
+    const uint32_t n = cam.width * cam.height;
+    hipLaunchKernelGGL(pt_direct_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, cam, accum, s0, count, seed);
+    return hipGetLastError();
+}

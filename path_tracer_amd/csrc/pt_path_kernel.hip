@@ -1,0 +1,539 @@
+// pt_path_kernel.hip — the FP32 `path` integrator for CDNA4 (gfx950, wave64), plus the
+// resolve pass and the FP32 VALU ceiling micro-benchmark.
+//
+// What it computes is the reference's renderKernel / traceRay
+// (cuda_pathtracer/src/raytracer_kernel.cu:202-305 with Material.cuh:36-259); how it computes
+// it is not the reference's one-thread-one-pixel-one-sample launch:
+//
+//  * persistent lanes with path regeneration: a wave owns a pool of 8x8 pixel tiles; every
+//    lane traces ONE ray per loop iteration and, the moment its path ends, starts its next
+//    sample / pulls its next pixel from the pool with a wave-level ballot+mbcnt prefix (no
+//    LDS, no atomics).  Bounce-count divergence (mirror corridors run to depth 50 with no
+//    Russian roulette) therefore costs idle lanes only in a wave's last few
+//    iterations, not on every path.
+//  * a pixel is owned by exactly one lane per launch: its samples are summed in registers in
+//    sample order and added to the float4 accumulation buffer with one 16-byte load and one
+//    16-byte store — deterministic, no float atomics.
+//  * the scene is read through wave-uniform indices, i.e. scalar loads into SGPRs (the scalar
+//    data cache is CDNA's constant memory); only the winning primitive is gathered per lane.
+//  * virtual dispatch is replaced by a material tag switch; curand by a counter RNG keyed on
+//    (pixel, sample, bounce) so a sample's value does not depend on which
+//    lane, launch or GPU traced it.
+//  * next-event estimation (template NEE) is a second ray KIND in the same loop, so shadow
+//    rays and path rays of different lanes share one intersection loop body.
+#include "pt_device.h"
+
+#include <float.h>
+
+namespace {
+
+constexpr uint32_t MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_GLOSSY = 3, MAT_EMISSIVE = 4;
+constexpr float RAY_MIN_T = 1e-4f;  // Ray.cuh:38
+constexpr float RAY_MAX_T = 1e4f;   // Ray.cuh:39
+constexpr float RAY_OFFSET = 0.001f;  // Material.cuh:64,115,173
+constexpr float INV_PI = 0.318309886183790671538f;
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float t) { return v3(a.x * t, a.y * t, a.z * t); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 u, V3 v) {
+    return v3(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// sin / cos of 2*pi*x: v_sin_f32 / v_cos_f32 take their argument in revolutions.
+__device__ __forceinline__ float sin2pi(float x) { return __builtin_amdgcn_sinf(x); }
+__device__ __forceinline__ float cos2pi(float x) { return __builtin_amdgcn_cosf(x); }
+__device__ __forceinline__ V3 normalized(V3 a) {  // Vec3.cuh:49-61
+    float l2 = dot(a, a);
+    return l2 > 0.0f ? a * rsq(l2) : a;
+}
+__device__ __forceinline__ V3 xyz(float4 f) { return v3(f.x, f.y, f.z); }
+
+// Counter RNG.  Two 32-bit multiplies per draw.
+__device__ __forceinline__ uint32_t pt_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t pt_draw(uint32_t key, uint32_t slot, uint32_t dim) {
+    return pt_hash(key + (slot * 8u + dim + 1u) * 0x9E3779B9U);
+}
+// (0,1], the range of curand_uniform which the reference's samplers are written for.
+__device__ __forceinline__ float uni(uint32_t bits) { return (float)((bits >> 8) + 1u) * (1.0f / 16777216.0f); }
+
+// ONB of Lambertian_t::scatter, Material.cuh:50-53
+__device__ __forceinline__ void onb(V3 w, V3& u, V3& v) {
+    V3 a = (fabsf(w.x) > 0.9f) ? v3(0, 1, 0) : v3(1, 0, 0);
+    v = normalized(cross(w, a));
+    u = cross(v, w);
+}
+
+// Closest hit over spheres, planes, triangles in that order with a strict '<'
+// (intersectScene, raytracer_kernel.cu:152-184).  Only (t, primitive id) are tracked; the hit
+// record is built once for the winner.  All scene operands are wave-uniform (SGPR) loads.
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, float& tbest, int& ibest,
+                                            uint32_t& n_roots) {
+    tbest = FLT_MAX;  // Scene.cuh:11
+    ibest = -1;
+    for (int i = 0; i < sc.ns; ++i) {  // intersectSphere, :44-78
+        const float4 s = sc.sph[i];
+        const V3 oc = v3(o.x - s.x, o.y - s.y, o.z - s.z);
+        const float half_b = dot(oc, d);
+        const float c = dot(oc, oc) - s.w;
+        const float disc = half_b * half_b - c;
+        if (disc >= 0.0f) {
+            if (COUNT) n_roots++;
+            const float sq = fsqrt(disc);
+            float root = -half_b - sq;
+            if (!(root >= RAY_MIN_T && root <= RAY_MAX_T)) root = -half_b + sq;
+            if (root >= RAY_MIN_T && root <= RAY_MAX_T && root < tbest) { tbest = root; ibest = i; }
+        }
+    }
+    for (int i = 0; i < sc.np; ++i) {  // intersectPlane, :80-103
+        const float4 n = sc.pl_n[i];
+        const float4 p = sc.pl_p[i];
+        const float denom = n.x * d.x + n.y * d.y + n.z * d.z;
+        const float num = (p.x - o.x) * n.x + (p.y - o.y) * n.y + (p.z - o.z) * n.z;
+        const float t = num * rcp(denom);
+        if (fabsf(denom) >= 1e-6f && t >= RAY_MIN_T && t <= RAY_MAX_T && t < tbest) { tbest = t; ibest = sc.ns + i; }
+    }
+    for (int i = 0; i < sc.nt; ++i) {  // intersectTriangle (Moller-Trumbore), :106-150
+        const V3 v0 = xyz(sc.tri[4 * i + 0]);
+        const V3 e1 = xyz(sc.tri[4 * i + 1]);
+        const V3 e2 = xyz(sc.tri[4 * i + 2]);
+        const V3 h = cross(d, e2);
+        const float a = dot(e1, h);
+        const float f = rcp(a);
+        const V3 s = o - v0;
+        const float u = f * dot(s, h);
+        const V3 q = cross(s, e1);
+        const float v = f * dot(d, q);
+        const float t = f * dot(e2, q);
+        const bool ok = fabsf(a) >= 1e-8f && u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f &&
+                        t >= RAY_MIN_T && t <= RAY_MAX_T;
+        if (ok && t < tbest) { tbest = t; ibest = sc.ns + sc.np + i; }
+    }
+}
+
+// Solid-angle pdf of picking one of nl sphere lights uniformly and sampling its cone from P.
+// Returns 0 when P is inside the light.  cosmax / wc / dc2 are by-products for the sampler.
+__device__ __forceinline__ float light_pdf(float4 lt, int nl, V3 P, float& cosmax, V3& wc, float& dc2) {
+    wc = v3(lt.x - P.x, lt.y - P.y, lt.z - P.z);
+    dc2 = dot(wc, wc);
+    cosmax = 0.0f;
+    if (!(dc2 > lt.w)) return 0.0f;
+    const float s2 = lt.w * rcp(dc2);
+    cosmax = fsqrt(fmaxf(0.0f, 1.0f - s2));
+    const float omc = s2 * rcp(1.0f + cosmax);  // 1 - cosmax without cancellation
+    return rcp(6.283185307179586f * omc * (float)nl);
+}
+
+__device__ __forceinline__ uint32_t pack_rgba8_cuda(float r, float g, float b) {  // Window.cuh:25-29
+    const uint32_t R = (uint32_t)fminf(fmaxf(r * 255.0f, 0.0f), 255.0f);
+    const uint32_t G = (uint32_t)fminf(fmaxf(g * 255.0f, 0.0f), 255.0f);
+    const uint32_t B = (uint32_t)fminf(fmaxf(b * 255.0f, 0.0f), 255.0f);
+    return (R << 16) | (G << 8) | B;
+}
+
+__device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <bool NEE, bool COUNT>
+__global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const DevCamF cam, const PathArgs a) {
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile0 = wave * a.tiles_per_wave;
+    if (tile0 >= a.num_tiles) return;  // whole wave leaves together
+    const uint32_t my_tiles = min(a.tiles_per_wave, a.num_tiles - tile0);
+    const uint32_t pool_size = my_tiles * 64u;
+    uint32_t pool_next = 0;  // wave-uniform
+
+    // lane state
+    int my = -1;             // pool index of the pixel this lane owns, -1 = none
+    uint32_t pixel = 0, px = 0, py = 0;
+    uint32_t sample_i = 0;   // samples of `pixel` started so far
+    bool alive = false;      // a path is in flight
+    V3 sum = v3(0, 0, 0);    // radiance sum of this pixel in this launch
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 1), beta = v3(1, 1, 1), L = v3(0, 0, 0);
+    uint32_t key = 0, depth = 0;
+    // NEE state
+    bool shadow = false, cont = false;
+    V3 pend_o = v3(0, 0, 0), pend_d = v3(0, 0, 1), contrib = v3(0, 0, 0);
+    int expect = -1;
+    float prev_pdf_b = -1.0f;
+    // counters (instrumented build only)
+    uint32_t c_samples = 0, c_rays = 0, c_hits = 0, c_roots = 0, c_b0 = 0, c_b1 = 0, c_b2 = 0, c_b3 = 0, c_b4 = 0,
+             c_diff = 0, c_nee = 0, c_shadow = 0;
+
+    for (;;) {
+        // ---- (1) finished pixels are flushed: one 16-B load + one 16-B store per pixel per launch
+        if (!alive && my >= 0 && sample_i == a.count) {
+            float4 acc;
+            if (a.acc_mode == 0u) {  // PT_ACC_SUM
+                acc = a.accum[pixel];
+                acc.x += sum.x; acc.y += sum.y; acc.z += sum.z; acc.w += (float)a.count;
+            } else {  // PT_ACC_RUNNING_MEAN, renderKernel :297-304 (count == 1, s0 = frame_count)
+                acc = make_float4(sum.x, sum.y, sum.z, 1.0f);
+                if (a.s0 > 0u) {
+                    const float4 prev = a.accum[pixel];
+                    const float t = a.mean_t;
+                    acc.x = sum.x * t + prev.x * (1.0f - t);
+                    acc.y = sum.y * t + prev.y * (1.0f - t);
+                    acc.z = sum.z * t + prev.z * (1.0f - t);
+                }
+            }
+            a.accum[pixel] = acc;
+            if (a.rgba) {  // fused convertToRGBAKernel
+                const float inv = (a.acc_mode == 0u) ? 1.0f / acc.w : 1.0f;
+                a.rgba[pixel] = pack_rgba8_cuda(acc.x * inv, acc.y * inv, acc.z * inv);
+            }
+            my = -1;
+        }
+        // ---- (2) lanes without a pixel pull the next one from the wave's pool
+        const bool want = !alive && my < 0;
+        const uint64_t want_mask = __ballot(want);
+        if (want_mask != 0ull && pool_next < pool_size) {
+            const uint32_t cand = pool_next + lane_prefix(want_mask);
+            if (want && cand < pool_size) {
+                const uint32_t tile = tile0 + (cand >> 6), li = cand & 63u;
+                const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+                px = tx * 8u + (li & 7u);
+                py = ty * 8u + (li >> 3);
+                if (px < cam.width && py < cam.height) {
+                    my = (int)cand;
+                    pixel = py * cam.width + px;
+                    sample_i = 0;
+                    sum = v3(0, 0, 0);
+                }
+            }
+            pool_next += (uint32_t)__popcll(want_mask);
+        }
+        // ---- (3) start the next sample of the owned pixel
+        if (!alive && my >= 0 && sample_i < a.count) {
+            key = pt_hash(pt_hash(pt_hash(a.seed) + pixel) + (a.s0 + sample_i));
+            sample_i++;
+            // renderKernel :286-291 + generateCameraRay :245-265
+            const float u = ((float)px + uni(pt_draw(key, 0, 0))) / (float)cam.width;
+            const float v = ((float)py + uni(pt_draw(key, 0, 1))) / (float)cam.height;
+            const float xo = (2.0f * u - 1.0f) * cam.half_w;
+            const float yo = (2.0f * v - 1.0f) * cam.half_h;
+            o = v3(cam.ox, cam.oy, cam.oz);
+            d = normalized(v3(cam.fx + cam.rx * xo + cam.ux * yo, cam.fy + cam.ry * xo + cam.uy * yo,
+                              cam.fz + cam.rz * xo + cam.uz * yo));
+            beta = v3(1, 1, 1);
+            L = v3(0, 0, 0);
+            depth = 0;
+            alive = true;
+            if (NEE) { shadow = false; prev_pdf_b = -1.0f; }
+            if (COUNT) c_samples++;
+        }
+        if (__ballot(alive) == 0ull) {
+            // nothing in flight: either every lane is out of work, or some lane still has to
+            // flush / pull (it will next iteration).  Done only when the pool is drained too.
+            if (__ballot(my >= 0) == 0ull && pool_next >= pool_size) break;
+            continue;
+        }
+        if (alive) {
+            // ---- (4) one ray
+            float t; int id;
+            closest_hit<COUNT>(sc, o, d, t, id, c_roots);
+            if (COUNT) { c_rays++; if (id >= 0) c_hits++; }
+            bool end_path = false;
+            if (id < 0) {
+                // miss: black background (:208).  A shadow ray that escapes is simply unoccluded-by-nothing: no light.
+                if (NEE && shadow) { shadow = false; if (cont) { o = pend_o; d = pend_d; } else end_path = true; }
+                else end_path = true;
+            } else {
+                // ---- (5) hit record of the winner (:66-71, :95-100, :142-147; Intersection.cuh:29-32)
+                const V3 p = o + d * t;
+                V3 n; uint32_t mat; float4 aux = make_float4(0, 0, 0, 0);
+                if (id < sc.ns) {
+                    const float4 s = sc.sph[id];
+                    aux = sc.sph_aux[id];
+                    n = (p - xyz(s)) * aux.x;
+                    mat = __float_as_uint(aux.y);
+                } else if (id < sc.ns + sc.np) {
+                    const float4 q = sc.pl_n[id - sc.ns];
+                    n = xyz(q); mat = __float_as_uint(q.w);
+                } else {
+                    const float4 q = sc.tri[4 * (id - sc.ns - sc.np) + 3];
+                    n = xyz(q); mat = __float_as_uint(q.w);
+                }
+                const bool front = dot(d, n) < 0.0f;
+                if (!front) n = -n;
+                const float4 ma = sc.mat_a[mat];
+                const uint32_t mtype = __float_as_uint(ma.w);
+                const V3 albedo = xyz(ma);
+
+                if (NEE && shadow) {
+                    // ---- shadow ray: the light is visible iff it is the closest hit, seen from outside
+                    if (id == expect && front) L = L + contrib;
+                    shadow = false;
+                    if (cont) { o = pend_o; d = pend_d; } else end_path = true;
+                } else {
+                    // ---- final_color += throughput * emitted (:211; Emissive_t::emitted, Material.cuh:254-258)
+                    if (mtype == MAT_EMISSIVE) {
+                        if (front) {
+                            V3 Le = xyz(sc.mat_e[mat]);
+                            if (a.light_colour && id < sc.ns && __float_as_uint(aux.w) != 0u) Le = xyz(sc.sph_em[id]);
+                            float w = 1.0f;
+                            if (NEE && prev_pdf_b >= 0.0f && id < sc.ns && (int)__float_as_uint(aux.z) >= 0) {
+                                const V3 P = o - d * RAY_OFFSET;  // apex = the previous hit point
+                                float cm, dc2; V3 wc;
+                                const float pl = light_pdf(sc.lights[(int)__float_as_uint(aux.z)], sc.nl, P, cm, wc, dc2);
+                                w = prev_pdf_b * rcp(prev_pdf_b + pl);
+                            }
+                            L = L + beta * Le * w;
+                        }
+                        if (COUNT) c_b4++;
+                        end_path = true;  // Emissive_t::scatter returns false
+                    } else if (mtype == MAT_LAMBERTIAN) {
+                        if (COUNT) c_b0++;
+                        const uint32_t slot = depth + 1u;
+                        bool do_shadow = false;
+                        if (NEE && sc.nl > 0) {
+                            // next-event estimation with balance-heuristic MIS (north_star addition)
+                            if (COUNT) c_nee++;
+                            const uint32_t j = __umulhi(pt_draw(key, slot, 4), (uint32_t)sc.nl);
+                            const float u1 = uni(pt_draw(key, slot, 5)), u2 = uni(pt_draw(key, slot, 6));
+                            float cosmax, dc2; V3 wc;
+                            const float pl = light_pdf(sc.lights[j], sc.nl, p, cosmax, wc, dc2);
+                            if (pl > 0.0f) {
+                                const float cost = 1.0f - u1 * (1.0f - cosmax);
+                                const float sint = fsqrt(fmaxf(0.0f, 1.0f - cost * cost));
+                                const V3 w = wc * rsq(dc2);
+                                V3 uu, vv; onb(w, uu, vv);
+                                const V3 dir = normalized(uu * (cos2pi(u2) * sint) + vv * (sin2pi(u2) * sint) + w * cost);
+                                const float cosN = dot(n, dir);
+                                if (cosN > 0.0f) {
+                                    const float pb = cosN * INV_PI;
+                                    const float wgt = pb * rcp(pl + pb);
+                                    const int ls = (int)sc.light_sphere[j];
+                                    const float4 la = sc.sph_aux[ls];
+                                    const uint32_t lm = __float_as_uint(la.y);
+                                    V3 Ls = xyz(sc.mat_e[lm]);
+                                    if (a.light_colour && __float_as_uint(la.w) != 0u) Ls = xyz(sc.sph_em[ls]);
+                                    contrib = beta * albedo * Ls * wgt;
+                                    expect = ls;
+                                    do_shadow = true;
+                                    pend_o = p + dir * RAY_OFFSET;  // shadow ray, same offset rule as a scattered ray
+                                    pend_d = dir;
+                                }
+                            }
+                        }
+                        // Lambertian_t::scatter, Material.cuh:43-70
+                        V3 uu, vv; onb(n, uu, vv);
+                        const float x1 = uni(pt_draw(key, slot, 0));
+                        const float r2 = uni(pt_draw(key, slot, 1));
+                        const float r2s = fsqrt(r2);
+                        const V3 dir = normalized(uu * (cos2pi(x1) * r2s) + vv * (sin2pi(x1) * r2s) + n * fsqrt(1.0f - r2));
+                        const float cosine = dot(n, dir);
+                        bool go = cosine > 0.0f;  // pdf > 0 (the reference's 0*inf NaN case ends the path)
+                        // throughput *= albedo * scatteringPdf / pdf  (:229-230; the ratio is 1)
+                        beta = beta * albedo;
+                        if (COUNT) { if (go) c_diff++; }
+                        if (go && depth > a.rr_depth) {  // :233-239
+                            const float pr = fmaxf(beta.x, fmaxf(beta.y, beta.z));
+                            if (uni(pt_draw(key, slot, 3)) > pr) go = false;
+                            else beta = beta * rcp(pr);
+                        }
+                        const V3 no = p + dir * RAY_OFFSET;
+                        if (NEE) {
+                            prev_pdf_b = cosine * INV_PI;
+                            if (do_shadow) {
+                                if (COUNT) c_shadow++;
+                                const V3 so = pend_o, sd = pend_d;
+                                pend_o = no; pend_d = dir;
+                                o = so; d = sd;
+                                shadow = true;
+                                cont = go && (depth + 1u < a.max_depth);
+                                go = true;  // the shadow ray is traced regardless
+                            } else { o = no; d = dir; }
+                        } else { o = no; d = dir; }
+                        if (!go) end_path = true;
+                    } else if (mtype == MAT_METAL) {
+                        // Metal_t::scatter, Material.cuh:97-121
+                        if (COUNT) c_b1++;
+                        const float rough = sc.mat_b[mat].x;
+                        V3 refl = d - n * (2.0f * dot(d, n));
+                        if (rough > 0.0f) {
+                            const uint32_t slot = depth + 1u;
+                            const V3 rnd = v3(uni(pt_draw(key, slot, 0)) * 2.0f - 1.0f, uni(pt_draw(key, slot, 1)) * 2.0f - 1.0f,
+                                              uni(pt_draw(key, slot, 2)) * 2.0f - 1.0f);
+                            refl = normalized(refl + rnd * rough);
+                        }
+                        refl = normalized(refl);  // Ray_t's constructor, Ray.cuh:43-53
+                        o = p + refl * RAY_OFFSET; d = refl;
+                        beta = beta * albedo;
+                        if (NEE) prev_pdf_b = -1.0f;
+                        if (!(dot(refl, n) > 0.0f)) end_path = true;
+                    } else if (mtype == MAT_DIELECTRIC) {
+                        // Dielectric_t::scatter, Material.cuh:149-175
+                        if (COUNT) c_b2++;
+                        const float ior = sc.mat_b[mat].z;
+                        const float eta = front ? rcp(ior) : ior;
+                        const float cos_theta = fminf(-dot(d, n), 1.0f);
+                        const float sin_theta = fsqrt(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
+                        const bool cannot = eta * sin_theta > 1.0f;
+                        float r0 = (1.0f - eta) * rcp(1.0f + eta); r0 *= r0;
+                        const float m1 = 1.0f - cos_theta, m2 = m1 * m1;
+                        const float sch = r0 + (1.0f - r0) * (m2 * m2 * m1);  // powf(1-cos, 5), :143
+                        V3 dir;
+                        if (cannot || sch > uni(pt_draw(key, depth + 1u, 0))) {
+                            dir = d - n * (2.0f * dot(d, n));
+                        } else {  // refract, :133-138
+                            const V3 perp = (d + n * cos_theta) * eta;
+                            const V3 par = n * -fsqrt(fabsf(1.0f - dot(perp, perp)));
+                            dir = perp + par;
+                        }
+                        dir = normalized(dir);
+                        o = p + dir * RAY_OFFSET; d = dir;
+                        if (NEE) prev_pdf_b = -1.0f;
+                    } else {
+                        // Glossy_t::scatter, Material.cuh:191-213
+                        if (COUNT) c_b3++;
+                        const float4 mb = sc.mat_b[mat];
+                        const V3 refl = d - n * (2.0f * dot(d, n));
+                        const uint32_t slot = depth + 1u;
+                        // Random_t::randomUnitVector, Random.cuh:36-45
+                        const float z = -1.0f + 2.0f * uni(pt_draw(key, slot, 0));
+                        const float tt = uni(pt_draw(key, slot, 1));
+                        const float r = fsqrt(fmaxf(0.0f, 1.0f - z * z));
+                        const V3 rv = normalized(v3(r * cos2pi(tt), r * sin2pi(tt), z));
+                        V3 sd = normalized(refl + rv * mb.x);
+                        if (dot(sd, n) < 0.0f) sd = refl;
+                        sd = normalized(sd);
+                        o = p; d = sd;  // no origin offset, :204
+                        const float m = mb.y;
+                        const V3 spec = m > 0.5f ? albedo : v3(1, 1, 1);
+                        beta = beta * v3(albedo.x * (1.0f - m) + spec.x * m, albedo.y * (1.0f - m) + spec.y * m,
+                                         albedo.z * (1.0f - m) + spec.z * m);
+                        if (NEE) prev_pdf_b = -1.0f;
+                    }
+                    // for (depth = 0; depth < max_depth; depth++), :206
+                    depth++;
+                    if (!(NEE && shadow) && depth >= a.max_depth) end_path = true;
+                }
+            }
+            if (end_path) { sum = sum + L; alive = false; }
+        }
+    }
+
+    if (COUNT && a.counters) {
+        uint32_t c[12] = {c_samples, c_rays, c_hits, c_roots, c_b0, c_b1, c_b2, c_b3, c_b4, c_diff, c_nee, c_shadow};
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            uint32_t v = c[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0 && v) atomicAdd((unsigned long long*)&a.counters[k], (unsigned long long)v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Resolve pass: accumulation buffer -> display buffer (convertToRGBAKernel, Window.cuh:16-30;
+// the CPU app's accumulate + gamma loop, main.cpp:223-237; Camera::saveImage, Camera.h:162-180).
+// One pixel per lane: a 16-B coalesced load, a 4-B (or 16-B / 3-B) store.
+__global__ __launch_bounds__(256) void pt_resolve_kernel(const float4* __restrict__ accum, void* __restrict__ out,
+                                                         uint32_t npix, uint32_t acc_mode, uint32_t mode) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= npix) return;
+    const float4 acc = accum[p];
+    float inv = 1.0f;
+    if (acc_mode == 0u) inv = acc.w > 0.0f ? 1.0f / acc.w : 0.0f;
+    const float r = acc.x * inv, g = acc.y * inv, b = acc.z * inv;
+    if (mode == 2u) {  // PT_RESOLVE_FLOAT_MEAN
+        ((float4*)out)[p] = make_float4(r, g, b, 1.0f);
+    } else if (mode == 0u) {  // PT_RESOLVE_RGBA8_CUDA
+        ((uint32_t*)out)[p] = pack_rgba8_cuda(r, g, b);
+    } else if (mode == 1u) {  // PT_RESOLVE_RGBA8_CPU: clamp, pow(1/2.2), *255 truncated
+        const float gr = powf(fminf(fmaxf(r, 0.0f), 1.0f), 1.0f / 2.2f);
+        const float gg = powf(fminf(fmaxf(g, 0.0f), 1.0f), 1.0f / 2.2f);
+        const float gb = powf(fminf(fmaxf(b, 0.0f), 1.0f), 1.0f / 2.2f);
+        ((uint32_t*)out)[p] = pack_rgba8_cuda(gr, gg, gb);
+    } else {  // PT_RESOLVE_RGB8_PPM: gamma, clamp, +0.5 rounding
+        uint8_t* o = (uint8_t*)out + 3ull * p;
+        const float c[3] = {r, g, b};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float gm = powf(fmaxf(c[k], 0.0f), 1.0f / 2.2f);
+            o[k] = (uint8_t)(fminf(fmaxf(gm, 0.0f), 1.0f) * 255.0f + 0.5f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// FP32 VALU ceiling: 16 independent FMA chains per lane, `iters` rounds.  packed != 0 runs the
+// chains as float2 so hipcc emits v_pk_fma_f32.  FLOPs = lanes * iters * 16 * 2.
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void pt_valu_peak_kernel(float* sink, uint32_t iters) {
+    const float s = (float)(threadIdx.x & 7u) * 1e-3f + 0.999f;
+    const float b = 1e-3f;
+    if (PACKED) {
+        float2v acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = float2v{(float)k, (float)k + 0.5f};
+        const float2v sv = {s, s + 1e-4f}, bv = {b, b};
+        for (uint32_t i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = __builtin_elementwise_fma(acc[k], sv, bv);
+        }
+        float r = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r += acc[k].x + acc[k].y;
+        if (r == 12345.678f) sink[0] = r;
+    } else {
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = (float)k;
+        for (uint32_t i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = __builtin_fmaf(acc[k], s, b);
+        }
+        float r = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r += acc[k];
+        if (r == 12345.678f) sink[0] = r;
+    }
+}
+
+}  // namespace
+
+hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArgs& a, bool nee, bool count,
+                          hipStream_t stream) {
+    const uint32_t waves = (a.num_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
+    const dim3 grid((waves + 3) / 4), block(256);
+    if (nee) {
+        if (count) hipLaunchKernelGGL((pt_path_kernel<true, true>), grid, block, 0, stream, sc, cam, a);
+        else hipLaunchKernelGGL((pt_path_kernel<true, false>), grid, block, 0, stream, sc, cam, a);
+    } else {
+        if (count) hipLaunchKernelGGL((pt_path_kernel<false, true>), grid, block, 0, stream, sc, cam, a);
+        else hipLaunchKernelGGL((pt_path_kernel<false, false>), grid, block, 0, stream, sc, cam, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint32_t acc_mode, uint32_t mode,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(pt_resolve_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, accum, out, npix, acc_mode, mode);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_valu_peak(float* sink, uint32_t packed, uint32_t iters, uint32_t blocks, hipStream_t stream) {
+    if (packed) hipLaunchKernelGGL((pt_valu_peak_kernel<true>), dim3(blocks), dim3(256), 0, stream, sink, iters);
+    else hipLaunchKernelGGL((pt_valu_peak_kernel<false>), dim3(blocks), dim3(256), 0, stream, sink, iters);
+    return hipGetLastError();
+}

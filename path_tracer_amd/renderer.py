@@ -1,0 +1,145 @@
+"""Thin Python driver of the C ABI (include/pt.h): one `Renderer` = one PtContext = one GPU.
+
+PyTorch is plumbing here: `bind_tensor()` makes a CUDA tensor the accumulation buffer (so
+torch.distributed / RCCL can reduce it) and `use_torch_stream()` enqueues the library's
+launches on torch's current stream (so torch.cuda.Event brackets them).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as abi
+from ._lib import check, lib
+
+
+def builtin_scene_from_library(name: str, width: int, height: int):
+    """The C++ host mirror's copy of a built-in scene (pt_builtin_scene); host only."""
+    s, c = abi.PtSceneSoA(), abi.PtCamera()
+    check(lib().pt_builtin_scene(name.encode(), width, height, C.byref(s), C.byref(c)))
+    cam = abi.PtCamera()
+    C.memmove(C.byref(cam), C.byref(c), C.sizeof(abi.PtCamera))
+    return abi.SceneArrays.from_struct(s), cam
+
+
+class Renderer:
+    def __init__(self, device: int = 0):
+        self._L = lib()
+        self._ctx = C.c_void_p()
+        check(self._L.pt_create(device, C.byref(self._ctx)))
+        self.width = self.height = 0
+        self._bound = None  # keeps a bound tensor alive
+
+    def close(self):
+        if self._ctx:
+            self._L.pt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- set-up ---------------------------------------------------------------------------
+    def set_scene(self, scene: abi.SceneArrays):
+        s = scene.struct()
+        check(self._L.pt_upload_scene(self._ctx, C.byref(s)))
+
+    def set_camera(self, cam: abi.PtCamera):
+        check(self._L.pt_set_camera(self._ctx, C.byref(cam)))
+        self.width, self.height = cam.width, cam.height
+        self._bound = None
+
+    def use_torch_stream(self):
+        import torch
+        check(self._L.pt_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def bind_tensor(self, t):
+        """t: contiguous float32 CUDA tensor [H, W, 4]; becomes the accumulation buffer."""
+        assert t.is_cuda and t.is_contiguous() and t.numel() == self.width * self.height * 4
+        check(self._L.pt_bind_accum(self._ctx, C.c_void_p(t.data_ptr())))
+        self._bound = t
+
+    def reset(self):
+        check(self._L.pt_reset(self._ctx))
+
+    # -- render ---------------------------------------------------------------------------
+    def render(self, sample_begin: int, sample_count: int, params: abi.PtRenderParams):
+        check(self._L.pt_render(self._ctx, sample_begin, sample_count, C.byref(params)))
+
+    def resolve(self, mode: int):
+        check(self._L.pt_resolve(self._ctx, mode))
+
+    def sync(self):
+        check(self._L.pt_sync(self._ctx))
+
+    def readback(self, mode: int) -> np.ndarray:
+        n = self.width * self.height
+        if mode == abi.RESOLVE_FLOAT_MEAN:
+            out = np.empty((self.height, self.width, 4), np.float32)
+        elif mode == abi.RESOLVE_RGB8_PPM:
+            out = np.empty((self.height, self.width, 3), np.uint8)
+        else:
+            out = np.empty((self.height, self.width), np.uint32)
+        assert out.size * out.itemsize in (n * 16, n * 3, n * 4)
+        check(self._L.pt_readback(self._ctx, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def resolve_to_host(self, mode: int) -> np.ndarray:
+        self.resolve(mode)
+        return self.readback(mode)
+
+    def accum(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), np.float32)
+        check(self._L.pt_readback_accum(self._ctx, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def upload_accum(self, a: np.ndarray):
+        a = np.ascontiguousarray(a, np.float32)
+        check(self._L.pt_upload_accum(self._ctx, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    # -- checks / measurement ---------------------------------------------------------------
+    def primary_ids(self):
+        obj = np.empty((self.height, self.width), np.uint32)
+        mat = np.empty((self.height, self.width), np.uint32)
+        check(self._L.pt_primary_ids(self._ctx, obj.ctypes.data_as(C.c_void_p), mat.ctypes.data_as(C.c_void_p)))
+        return obj, mat
+
+    def counters(self) -> abi.PtCounters:
+        c = abi.PtCounters()
+        check(self._L.pt_counters(self._ctx, C.byref(c)))
+        return c
+
+    def reset_counters(self):
+        check(self._L.pt_reset_counters(self._ctx))
+
+    def valu_peak(self, packed: bool, iters: int = 1 << 16) -> float:
+        out = C.c_double()
+        check(self._L.pt_valu_peak(self._ctx, int(packed), iters, C.byref(out)))
+        return out.value
+
+    def launch_render_kernel(self, dev_ptr: int, frame_count: int):
+        """The reference's call shape: launchRenderKernel(output, w, h, frame_count, grid, block)."""
+        check(self._L.pt_make_current(self._ctx))
+        self._L.launchRenderKernel(C.c_void_p(dev_ptr), self.width, self.height, frame_count, 0, 0, 0, 16, 16, 1)
+
+
+# --- FLOP model of SURVEY.md §8(d) ------------------------------------------------------
+FLOP_TABLE = dict(sphere=16, sphere_root=3, plane=14, triangle=51, hit_record=20, camera=30,
+                  lambert=70, metal=20, dielectric=60, glossy=50, diffuse_update=12, nee=40, accumulate=10)
+
+
+def algorithmic_flops(cnt: dict, ns: int, np_: int, nt: int, pixel_launches: int) -> float:
+    """Algorithmic FLOPs of a render from its event counters (fixed cost table)."""
+    T = FLOP_TABLE
+    b = cnt["bounces"]
+    f = cnt["samples"] * T["camera"]
+    f += cnt["rays"] * (ns * T["sphere"] + np_ * T["plane"] + nt * T["triangle"])
+    f += cnt["sphere_roots"] * T["sphere_root"] + cnt["hits"] * T["hit_record"]
+    f += b[abi.MAT_LAMBERTIAN] * T["lambert"] + b[abi.MAT_METAL] * T["metal"]
+    f += b[abi.MAT_DIELECTRIC] * T["dielectric"] + b[abi.MAT_GLOSSY] * T["glossy"]
+    f += cnt["diffuse_updates"] * T["diffuse_update"] + cnt["nee_samples"] * T["nee"]
+    f += pixel_launches * T["accumulate"]
+    return float(f)

@@ -1,0 +1,100 @@
+// pt_headless — headless frame-dump driver: the reference's frame loops (main.cu:284-303,
+// main.cpp:153-249) without X11.  Builds a scene with the host mirror of the reference's
+// interfaces, renders progressively through the C ABI, writes a P6 PPM (gamma 2.2, +0.5
+// rounding — Camera::saveImage, cpu_pathtracer/include/Camera.h:162-180) and/or the raw
+// float4 accumulation buffer (sum r,g,b, sample count) that pt_upload_accum can resume from.
+#include "pt_host.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static void usage() {
+    std::puts(
+        "usage: pt_headless [--scene cuda_default|cpu_default|glass_stress|random4096] [--width W] [--height H]\n"
+        "                   [--spp N] [--spp-per-launch K] [--max-depth D] [--integrator path|direct] [--seed S]\n"
+        "                   [--mis] [--light-colour] [--device I] [--resume raw] [--out image.ppm] [--raw accum.f32]");
+}
+
+int main(int argc, char** argv) {
+    std::string scene = "cuda_default", integrator, out, raw, resume;
+    uint32_t W = 1280, H = 720, spp = 64, per = 0, depth = 0, seed = 0x5EED0001u, flags = 0;
+    int device = 0;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char* { if (i + 1 >= argc) { usage(); std::exit(2); } return argv[++i]; };
+        if (a == "--scene") scene = next();
+        else if (a == "--width") W = (uint32_t)std::atoi(next());
+        else if (a == "--height") H = (uint32_t)std::atoi(next());
+        else if (a == "--spp") spp = (uint32_t)std::atoi(next());
+        else if (a == "--spp-per-launch") per = (uint32_t)std::atoi(next());
+        else if (a == "--max-depth") depth = (uint32_t)std::atoi(next());
+        else if (a == "--integrator") integrator = next();
+        else if (a == "--seed") seed = (uint32_t)std::strtoul(next(), nullptr, 0);
+        else if (a == "--mis") flags |= PT_FLAG_NEE_MIS;
+        else if (a == "--light-colour") flags |= PT_FLAG_LIGHT_COLOUR;
+        else if (a == "--device") device = std::atoi(next());
+        else if (a == "--out") out = next();
+        else if (a == "--raw") raw = next();
+        else if (a == "--resume") resume = next();
+        else { usage(); return a == "--help" ? 0 : 2; }
+    }
+    try {
+        PtSceneSoA s; PtCamera c;
+        if (pt_builtin_scene(scene.c_str(), W, H, &s, &c) != PT_OK) { std::fprintf(stderr, "unknown scene %s\n", scene.c_str()); return 2; }
+        if (integrator.empty()) integrator = scene == "cpu_default" ? "direct" : "path";
+        PtRenderParams p = pt::defaultParams();
+        p.integrator = integrator == "direct" ? PT_INTEGRATOR_DIRECT : PT_INTEGRATOR_PATH;
+        p.seed = seed; p.flags = flags;
+        p.max_depth = depth ? depth : (scene == "glass_stress" ? 32u : scene == "random4096" ? 16u : 50u);
+        if (p.integrator == PT_INTEGRATOR_PATH) c.model = PT_CAMERA_CUDA;
+        if (per == 0) per = spp < 16 ? spp : 16;
+
+        pt::Renderer r(device);
+        r.setScene(s);
+        r.setCamera(c);
+        const size_t npix = (size_t)W * H;
+        uint32_t begin = 0;
+        if (!resume.empty()) {  // raw (sum, count) checkpoint
+            std::vector<float> acc(npix * 4);
+            FILE* f = std::fopen(resume.c_str(), "rb");
+            if (!f || std::fread(acc.data(), 4, acc.size(), f) != acc.size()) { std::fprintf(stderr, "cannot read %s\n", resume.c_str()); return 1; }
+            std::fclose(f);
+            pt::check(pt_upload_accum(r.ctx(), acc.data(), acc.size() * 4));
+            begin = (uint32_t)acc[3];
+        }
+        r.sync();
+        auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t sdone = 0; sdone < spp; sdone += per) r.render(begin + sdone, std::min(per, spp - sdone), p);
+        r.sync();
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("{\"scene\": \"%s\", \"integrator\": \"%s\", \"width\": %u, \"height\": %u, \"spp\": %u, \"seconds\": %.6f, "
+                    "\"msamples_per_s\": %.3f}\n", scene.c_str(), integrator.c_str(), W, H, spp, sec, npix * (double)spp / sec / 1e6);
+        if (!out.empty()) {
+            r.resolve(PT_RESOLVE_RGB8_PPM);
+            std::vector<unsigned char> img(npix * 3);
+            r.readback(img.data(), img.size());
+            FILE* f = std::fopen(out.c_str(), "wb");
+            if (!f) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+            std::fprintf(f, "P6\n%u %u\n255\n", W, H);
+            std::fwrite(img.data(), 1, img.size(), f);
+            std::fclose(f);
+        }
+        if (!raw.empty()) {
+            std::vector<float> acc(npix * 4);
+            r.readbackAccum(acc.data(), acc.size() * 4);
+            FILE* f = std::fopen(raw.c_str(), "wb");
+            if (!f) { std::fprintf(stderr, "cannot write %s\n", raw.c_str()); return 1; }
+            std::fwrite(acc.data(), 4, acc.size(), f);
+            std::fclose(f);
+        }
+    } catch (const pt::Error& e) {
+        std::fprintf(stderr, "pt error %d: %s\n", e.code, e.what());
+        return 1;
+    }
+    return 0;
+}
