@@ -37,6 +37,13 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950); "
                           "there is no CPU fallback for the render path")
+    # torch bundles its own HIP runtime (soname libamdhip64.so.7).  Loading it FIRST makes this
+    # library's NEEDED entry resolve to that same copy; the other order puts two HIP runtimes in
+    # one process and torch then reports "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     ctx, u32, vp = C.c_void_p, C.c_uint32, C.c_void_p
     L.pt_create.argtypes = [C.c_int, C.POINTER(ctx)]

@@ -552,6 +552,7 @@ void launchRenderKernel(void* output, uint32_t width, uint32_t height, uint32_t 
                         uint32_t, uint32_t, uint32_t) {
     PtContext* ctx = g_current;
     if (!ctx) { fail(PT_ERR_STATE, "launchRenderKernel: no current context (pt_make_current)"); return; }
+    if (!output) { fail(PT_ERR_INVALID, "launchRenderKernel: output is null"); return; }
     if (width != ctx->width || height != ctx->height) { fail(PT_ERR_INVALID, "launchRenderKernel: %ux%u does not match the camera's %ux%u", width, height, ctx->width, ctx->height); return; }
     float4* saved = ctx->accum;
     const bool saved_bound = ctx->accum_bound;

@@ -36,12 +36,12 @@ struct DRay { D3 o, d; double min_t, max_t; };
 __device__ __forceinline__ DRay make_ray(D3 o, D3 d) { return DRay{o, normalized(d), 1e-8, 1e30}; }
 __device__ __forceinline__ bool valid_t(const DRay& r, double t) { return t >= r.min_t && t <= r.max_t; }  // Ray.h:192-194
 
-struct DHit { bool hit; double t; uint32_t obj; int kind; int prim; };
+struct DHit { bool hit; double t; uint32_t obj; uint32_t mat; int kind; int prim; };
 
 // Closest hit in INSERTION order with a strict '<' (Scene.h:57-69): the SoA splits objects by
 // class, so exact distance ties go to the smaller object id.
-__device__ __forceinline__ void consider(DHit& best, double t, uint32_t obj, int kind, int prim) {
-    if (!best.hit || t < best.t || (t == best.t && obj < best.obj)) best = DHit{true, t, obj, kind, prim};
+__device__ __forceinline__ void consider(DHit& best, double t, uint32_t obj, uint32_t mat, int kind, int prim) {
+    if (!best.hit || t < best.t || (t == best.t && obj < best.obj)) best = DHit{true, t, obj, mat, kind, prim};
 }
 
 __device__ __forceinline__ bool sphere_t(const double* s, const DRay& ray, double& root) {  // ImplicitObject.h:57-79
@@ -83,10 +83,10 @@ __device__ __forceinline__ bool tri_t(const double* v, const DRay& ray, double& 
 }
 
 __device__ DHit scene_hit(const DevSceneD& sc, const DRay& ray) {
-    DHit best{false, 0.0, 0u, 0, 0};
-    for (int i = 0; i < sc.ns; ++i) { double t; if (sphere_t(sc.sph + 4 * i, ray, t)) consider(best, t, sc.sph_info[3 * i + 1], 0, i); }
-    for (int i = 0; i < sc.np; ++i) { double t; if (plane_t(sc.pl + 6 * i, ray, t)) consider(best, t, sc.pl_info[2 * i + 1], 1, i); }
-    for (int i = 0; i < sc.nt; ++i) { double t; if (tri_t(sc.tri + 9 * i, ray, t)) consider(best, t, sc.tri_info[2 * i + 1], 2, i); }
+    DHit best{false, 0.0, 0u, 0xFFFFFFFFu, 0, 0};
+    for (int i = 0; i < sc.ns; ++i) { double t; if (sphere_t(sc.sph + 4 * i, ray, t)) consider(best, t, sc.sph_info[3 * i + 1], sc.sph_info[3 * i], 0, i); }
+    for (int i = 0; i < sc.np; ++i) { double t; if (plane_t(sc.pl + 6 * i, ray, t)) consider(best, t, sc.pl_info[2 * i + 1], sc.pl_info[2 * i], 1, i); }
+    for (int i = 0; i < sc.nt; ++i) { double t; if (tri_t(sc.tri + 9 * i, ray, t)) consider(best, t, sc.tri_info[2 * i + 1], sc.tri_info[2 * i], 2, i); }
     return best;
 }
 
@@ -112,10 +112,8 @@ __global__ __launch_bounds__(256) void pt_primary_ids_kernel(const DevSceneD sc,
     const uint32_t y = p / cam.width, x = p - y * cam.width;
     const DRay ray = camera_ray(cam, x, y, 0.5, 0.5);  // getRayForPixel(x, y, false)
     const DHit h = scene_hit(sc, ray);
-    uint32_t m = 0xFFFFFFFFu;
-    if (h.hit) m = h.kind == 0 ? sc.sph_info[3 * h.prim] : h.kind == 1 ? sc.pl_info[2 * h.prim] : sc.tri_info[2 * h.prim];
     if (obj) obj[p] = h.hit ? h.obj : 0xFFFFFFFFu;
-    if (mat) mat[p] = m;
+    if (mat) mat[p] = h.hit ? h.mat : 0xFFFFFFFFu;
 }
 
 // Counter RNG
@@ -162,16 +160,15 @@ __global__ __launch_bounds__(256) void pt_direct_kernel(const DevSceneD sc, cons
         }
         // hit record of the winner
         const D3 hp = ray.o + ray.d * h.t;
-        D3 n; uint32_t m;
+        D3 n; const uint32_t m = h.mat;
         if (h.kind == 0) {
             const double* s = sc.sph + 4 * h.prim;
             n = (hp - d3(s[0], s[1], s[2])) * (1 / s[3]);  // getNormalAt, ImplicitObject.h:97-99 + Vec3.h:118-121
-            m = sc.sph_info[3 * h.prim];
         } else if (h.kind == 1) {
-            n = ld3(sc.pl + 6 * h.prim + 3); m = sc.pl_info[2 * h.prim];
+            n = ld3(sc.pl + 6 * h.prim + 3);
         } else {
             const double* v = sc.tri + 9 * h.prim;
-            n = normalized(cross(ld3(v + 3) - ld3(v), ld3(v + 6) - ld3(v))); m = sc.tri_info[2 * h.prim];
+            n = normalized(cross(ld3(v + 3) - ld3(v), ld3(v + 6) - ld3(v)));
         }
         if (!(dot(ray.d, n) < 0)) n = -n;  // setFaceNormal, Intersection.h:16-19
         double direct[3] = {0, 0, 0};

@@ -49,12 +49,20 @@ class Renderer:
 
     def set_camera(self, cam: abi.PtCamera):
         check(self._L.pt_set_camera(self._ctx, C.byref(cam)))
+        if (cam.width, cam.height) != (self.width, self.height):
+            self._bound = None  # the library drops a bound buffer when the frame size changes
         self.width, self.height = cam.width, cam.height
-        self._bound = None
 
     def use_torch_stream(self):
         import torch
         check(self._L.pt_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def use_own_stream(self):
+        check(self._L.pt_set_stream(self._ctx, None))
+
+    def unbind(self):
+        check(self._L.pt_bind_accum(self._ctx, None))
+        self._bound = None
 
     def bind_tensor(self, t):
         """t: contiguous float32 CUDA tensor [H, W, 4]; becomes the accumulation buffer."""

@@ -1,0 +1,65 @@
+"""The C-ABI shared library loads on a machine without a GPU and exports every symbol that
+include/pt.h declares.  No compute call is made here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+from path_tracer_amd import _lib, abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+char\s*\*|int|void\s*\*|void|uint32_t)\s+(\w+)\s*\(", text, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_and_binding_list_the_same_symbols():
+    assert _declared_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    for name in _declared_symbols():
+        assert getattr(L, name) is not None
+    assert L.pt_abi_version() == 1
+
+
+def test_struct_sizes_match_the_header(tmp_path):
+    """sizeof / offsetof as gcc sees include/pt.h == what the ctypes mirror declares."""
+    src = tmp_path / "sizes.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "pt.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(PtSceneSoA), sizeof(PtCamera),'
+        ' sizeof(PtRenderParams), sizeof(PtCounters), offsetof(PtSceneSoA, mat_type), offsetof(PtCamera, width),'
+        ' offsetof(PtCounters, diffuse_updates)); return 0;}\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [C.sizeof(abi.PtSceneSoA), C.sizeof(abi.PtCamera), C.sizeof(abi.PtRenderParams), C.sizeof(abi.PtCounters),
+            abi.PtSceneSoA.mat_type.offset, abi.PtCamera.width.offset, abi.PtCounters.diffuse_updates.offset]
+    assert got == want
+
+
+def test_host_only_entry_points():
+    L = _lib.lib()
+    s, c = abi.PtSceneSoA(), abi.PtCamera()
+    assert L.pt_builtin_scene(b"no_such_scene", 64, 64, C.byref(s), C.byref(c)) == abi.PT_ERR_INVALID
+    assert L.pt_builtin_scene(b"cuda_default", 0, 64, C.byref(s), C.byref(c)) == abi.PT_ERR_INVALID
+    assert L.pt_builtin_scene(b"cuda_default", 64, 36, C.byref(s), C.byref(c)) == 0
+    assert s.num_spheres == 9 and c.width == 64
+    assert L.pt_destroy(None) == 0  # destroying nothing is not an error
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product path must not import, link or load anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "path_tracer_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pt_oracle" not in text and "oracle_binding" not in text and "libpt_oracle" not in text, f
+    out = os.popen(f"ldd {_lib.LIB_PATH}").read()
+    assert "oracle" not in out
