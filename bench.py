@@ -181,7 +181,7 @@ def cpu_baseline(scene, cam, params, spp, budget_s):
     t = time.perf_counter()
     acc = o.render_path(scene, cam, 0, spp, p, precision=32)
     one = time.perf_counter() - t
-    frames = max(1, min(64, int(budget_s / max(one, 1e-3)) - 1))
+    frames = max(1, min(512, int(budget_s / max(one, 1e-3)) - 1))
     t = time.perf_counter()
     for f in range(frames):
         o.render_path(scene, cam, (1 + f) * spp, spp, p, precision=32, accum=acc)

@@ -185,8 +185,11 @@ const char* pt_last_error(void);
 uint32_t pt_abi_version(void);
 
 /* Use an existing HIP stream (e.g. torch's current stream) for all work of the
- * context; NULL restores the context's own stream. */
+ * context.  NULL is HIP's null (legacy default) stream, which is what torch's
+ * default stream is.  pt_use_own_stream() goes back to the context's own
+ * non-blocking stream. */
 int pt_set_stream(PtContext* ctx, void* hip_stream);
+int pt_use_own_stream(PtContext* ctx);
 
 /* -- scene / camera -------------------------------------------------------- */
 /* Replaces MaterialFactory::createMaterialsOnDevice (MaterialFactory.cuh:41-75),

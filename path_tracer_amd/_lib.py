@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libp
 
 # every extern "C" symbol include/pt.h declares (tests check the export list against the header)
 SYMBOLS = [
-    "pt_create", "pt_destroy", "pt_last_error", "pt_abi_version", "pt_set_stream", "pt_upload_scene",
+    "pt_create", "pt_destroy", "pt_last_error", "pt_abi_version", "pt_set_stream", "pt_use_own_stream", "pt_upload_scene",
     "pt_set_camera", "pt_resize", "pt_bind_accum", "pt_reset", "pt_render", "pt_resolve", "pt_readback",
     "pt_readback_accum", "pt_upload_accum", "pt_sync", "pt_accum_device_ptr", "pt_display_device_ptr",
     "pt_primary_ids", "pt_counters", "pt_reset_counters", "pt_valu_peak", "pt_make_current",
@@ -51,6 +51,7 @@ def lib() -> C.CDLL:
     L.pt_last_error.restype = C.c_char_p
     L.pt_abi_version.restype = u32
     L.pt_set_stream.argtypes = [ctx, vp]
+    L.pt_use_own_stream.argtypes = [ctx]
     L.pt_upload_scene.argtypes = [ctx, C.POINTER(abi.PtSceneSoA)]
     L.pt_set_camera.argtypes = [ctx, C.POINTER(abi.PtCamera)]
     L.pt_resize.argtypes = [ctx, u32, u32]

@@ -165,7 +165,13 @@ int pt_destroy(PtContext* ctx) {
 
 int pt_set_stream(PtContext* ctx, void* hip_stream) {
     if (int rc = use(ctx)) return rc;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;
+    return PT_OK;
+}
+
+int pt_use_own_stream(PtContext* ctx) {
+    if (int rc = use(ctx)) return rc;
+    ctx->stream = ctx->own_stream;
     return PT_OK;
 }
 

@@ -58,7 +58,7 @@ class Renderer:
         check(self._L.pt_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     def use_own_stream(self):
-        check(self._L.pt_set_stream(self._ctx, None))
+        check(self._L.pt_use_own_stream(self._ctx))
 
     def unbind(self):
         check(self._L.pt_bind_accum(self._ctx, None))
