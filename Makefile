@@ -6,6 +6,10 @@ CSRC    := path_tracer_amd/csrc
 HOST    := path_tracer_amd/host
 LIBDIR  := path_tracer_amd/lib
 LIB     := $(LIBDIR)/libpt_amd.so
+# -fno-slp-vectorize: hipcc otherwise packs adjacent scalar f32 ops into v_pk_* plus v_mov shuffles;
+# v_pk_fma_f32 issues at half the rate of v_fma_f32 on gfx950, so packing only adds instructions
+# (measured +15..20 % Msamples/s without it, profiles/r1_variants.json)
+KFLAGS  ?= -fno-slp-vectorize
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude
 OBJS    := build/pt_api.o build/pt_path_kernel.o build/pt_f64_kernels.o build/pt_builtin_scenes.o
 
@@ -21,7 +25,7 @@ build/pt_api.o: $(CSRC)/pt_api.cpp $(CSRC)/pt_device.h include/pt.h
 
 build/pt_path_kernel.o: $(CSRC)/pt_path_kernel.hip $(CSRC)/pt_device.h
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -c $< -o $@
 
 # FP64 kernels: no FMA contraction, so every operation is one IEEE double op (bit-exact ids)
 build/pt_f64_kernels.o: $(CSRC)/pt_f64_kernels.hip $(CSRC)/pt_device.h
@@ -47,3 +51,9 @@ clean:
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean isa
+
+# kernel-variant build for A/B runs:  make variant NAME=v1 KFLAGS="-fno-slp-vectorize"
+variant: build/pt_api.o build/pt_f64_kernels.o build/pt_builtin_scenes.o
+	@mkdir -p build/var_$(NAME)
+	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -c $(CSRC)/pt_path_kernel.hip -o build/var_$(NAME)/pt_path_kernel.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libpt_amd_$(NAME).so build/pt_api.o build/var_$(NAME)/pt_path_kernel.o build/pt_f64_kernels.o build/pt_builtin_scenes.o

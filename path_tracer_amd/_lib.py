@@ -10,7 +10,8 @@ import os
 
 from . import _abi as abi
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpt_amd.so")
+# PT_AMD_LIB selects another build of the SAME library (kernel-variant A/B runs); never a fallback
+LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpt_amd.so")
 
 # every extern "C" symbol include/pt.h declares (tests check the export list against the header)
 SYMBOLS = [

@@ -214,6 +214,7 @@ int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
     auto push4 = [&](float x, float y, float z, float w) { f4.push_back(make_float4(x, y, z, w)); };
     const size_t o_sph = f4.size();
     for (uint32_t i = 0; i < ns; ++i) { float r = (float)s->sph_r[i]; push4((float)s->sph_cx[i], (float)s->sph_cy[i], (float)s->sph_cz[i], r * r); }
+    for (uint32_t i = ns; i % 4 != 0 || i == 0; ++i) push4(0, 0, 0, -1.0f);  // padding: r*r < 0 gives disc < 0 for every ray
     const size_t o_aux = f4.size();
     for (uint32_t i = 0; i < ns; ++i) {
         float r = (float)s->sph_r[i];
@@ -221,13 +222,13 @@ int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
     }
     const size_t o_sem = f4.size();
     for (uint32_t i = 0; i < ns; ++i) push4((float)s->sph_em_r[i], (float)s->sph_em_g[i], (float)s->sph_em_b[i], 0.f);
-    const size_t o_plp = f4.size();
-    for (uint32_t i = 0; i < np; ++i) push4((float)s->pl_px[i], (float)s->pl_py[i], (float)s->pl_pz[i], 0.f);
-    const size_t o_pln = f4.size();
+    const size_t o_pl = f4.size();
     for (uint32_t i = 0; i < np; ++i) {  // Plane_t's constructor normalises in float (ImplicitObject.cuh:165)
         F3 n = fnorm(F3{(float)s->pl_nx[i], (float)s->pl_ny[i], (float)s->pl_nz[i]});
         push4(n.x, n.y, n.z, u2f(s->pl_mat[i]));
+        push4((float)s->pl_px[i], (float)s->pl_py[i], (float)s->pl_pz[i], 0.f);
     }
+    for (uint32_t i = np; i % 2 != 0 || i == 0; ++i) { push4(0, 0, 0, 0); push4(0, 0, 0, 0); }  // padding: denom == 0 never hits
     const size_t o_tri = f4.size();
     for (uint32_t i = 0; i < nt; ++i) {
         F3 v0{(float)s->tri_v0x[i], (float)s->tri_v0y[i], (float)s->tri_v0z[i]};
@@ -238,6 +239,7 @@ int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
         push4(v0.x, v0.y, v0.z, 0.f); push4(e1.x, e1.y, e1.z, 0.f); push4(e2.x, e2.y, e2.z, 0.f);
         push4(n.x, n.y, n.z, u2f(s->tri_mat[i]));
     }
+    for (uint32_t i = nt; i % 2 != 0 || i == 0; ++i) for (int k = 0; k < 4; ++k) push4(0, 0, 0, 0);  // padding: a == 0 never hits
     const size_t o_ma = f4.size();
     for (uint32_t i = 0; i < nm; ++i) push4((float)s->mat_albedo_r[i], (float)s->mat_albedo_g[i], (float)s->mat_albedo_b[i], u2f(s->mat_type[i]));
     const size_t o_mb = f4.size();
@@ -305,7 +307,7 @@ int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
     const uint32_t* U = (const uint32_t*)((const unsigned char*)ctx->scene_arena + b_f4);
     const double* D = (const double*)((const unsigned char*)ctx->scene_arena + b_f4 + b_u32);
     DevSceneF& sf = ctx->sf;
-    sf.sph = F + o_sph; sf.sph_aux = F + o_aux; sf.sph_em = F + o_sem; sf.pl_p = F + o_plp; sf.pl_n = F + o_pln;
+    sf.sph = F + o_sph; sf.sph_aux = F + o_aux; sf.sph_em = F + o_sem; sf.pl = F + o_pl;
     sf.tri = F + o_tri; sf.mat_a = F + o_ma; sf.mat_b = F + o_mb; sf.mat_e = F + o_me; sf.lights = F + o_lt;
     sf.light_sphere = U + o_ls; sf.obj_ids = U + o_obj;
     sf.ns = (int)ns; sf.np = (int)np; sf.nt = (int)nt; sf.nl = (int)nl;

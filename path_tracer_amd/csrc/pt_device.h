@@ -11,11 +11,12 @@
 
 // ---- FP32 scene for the `path` kernel -------------------------------------------------
 struct DevSceneF {
+    // Loop operands are padded with never-hit primitives: sph to a multiple of 4, pl and tri to a
+    // multiple of 2 entries, so the intersection loops fetch whole batches (scalar loads).
     const float4* sph;      // [ns]  cx, cy, cz, r*r            (loop operand, scalar loads)
     const float4* sph_aux;  // [ns]  1/r, bits(mat), bits(light index | -1), bits(makeEmissive flag)
     const float4* sph_em;   // [ns]  makeEmissive colour*strength, 0
-    const float4* pl_p;     // [np]  point, 0                     (loop operand)
-    const float4* pl_n;     // [np]  unit normal, bits(mat)       (loop operand; .w used by winner)
+    const float4* pl;       // [2*np] unit normal, bits(mat) | point, 0   (loop operand; normal also gathered by the winner)
     const float4* tri;      // [4*nt] v0 | e1=v1-v0 | e2=v2-v0 | unit normal, bits(mat)
     const float4* mat_a;    // [nm]  albedo rgb, bits(type)
     const float4* mat_b;    // [nm]  roughness (clamped for Metal), metallic, ior, 0

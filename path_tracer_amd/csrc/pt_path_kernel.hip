@@ -76,51 +76,106 @@ __device__ __forceinline__ void onb(V3 w, V3& u, V3& v) {
     u = cross(v, w);
 }
 
+// Scene operands of the intersection loops are read through the CONSTANT address space with a
+// wave-uniform index: hipcc then emits scalar loads (s_load_dwordx4/x8/x16 through the scalar
+// data cache) and the operands live in SGPRs.  Through a plain global pointer it emits one
+// vector load plus an s_waitcnt vmcnt(0) per primitive, i.e. a serialized L2 round trip per
+// test (profiles/r1_baseline: 0.51 ms per 720p frame).  The scene arena is written only by
+// pt_upload_scene, never by a kernel, so the constant view is valid.
+#define PT_CONST __attribute__((address_space(4)))
+typedef float f4v __attribute__((ext_vector_type(4)));  // HIP's float4 class cannot be read from address space 4
+typedef const PT_CONST f4v* cf4;
+__device__ __forceinline__ cf4 as_const(const float4* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (cf4)p;
+#pragma clang diagnostic pop
+}
+
+#ifndef PT_SPHERE_BRANCHFREE
+#define PT_SPHERE_BRANCHFREE 0
+#endif
+template <bool COUNT>
+__device__ __forceinline__ void sphere_test(const f4v s, int i, V3 o, V3 d, float& tbest, int& ibest, uint32_t& n_roots) {
+    // intersectSphere, raytracer_kernel.cu:44-78
+    const V3 oc = v3(o.x - s.x, o.y - s.y, o.z - s.z);
+    const float half_b = dot(oc, d);
+    const float c = dot(oc, oc) - s.w;
+    const float disc = half_b * half_b - c;
+#if PT_SPHERE_BRANCHFREE
+    // No branch: sqrt of a negative discriminant is NaN, every comparison with NaN is false, so
+    // a missed sphere falls through the selects.  (A taken branch costs this kernel more than the
+    // eight predicated instructions it would skip: 33 branches per ray in the r1 baseline.)
+    if (COUNT) n_roots += disc >= 0.0f ? 1u : 0u;
+    const float sq = fsqrt(disc);
+    const float r0 = -half_b - sq, r1 = sq - half_b;
+    const float root = (r0 >= RAY_MIN_T && r0 <= RAY_MAX_T) ? r0 : r1;
+    const bool ok = root >= RAY_MIN_T && root <= RAY_MAX_T && root < tbest;
+    tbest = ok ? root : tbest;
+    ibest = ok ? i : ibest;
+#else
+    if (disc >= 0.0f) {
+        if (COUNT) n_roots++;
+        const float sq = fsqrt(disc);
+        float root = -half_b - sq;
+        if (!(root >= RAY_MIN_T && root <= RAY_MAX_T)) root = -half_b + sq;
+        if (root >= RAY_MIN_T && root <= RAY_MAX_T && root < tbest) { tbest = root; ibest = i; }
+    }
+#endif
+}
+
+__device__ __forceinline__ void plane_test(const f4v n, const f4v p, int id, V3 o, V3 d, float& tbest, int& ibest) {
+    // intersectPlane, raytracer_kernel.cu:80-103
+    const float denom = n.x * d.x + n.y * d.y + n.z * d.z;
+    const float num = (p.x - o.x) * n.x + (p.y - o.y) * n.y + (p.z - o.z) * n.z;
+    const float t = num * rcp(denom);
+    if (fabsf(denom) >= 1e-6f && t >= RAY_MIN_T && t <= RAY_MAX_T && t < tbest) { tbest = t; ibest = id; }
+}
+
+__device__ __forceinline__ void tri_test(const f4v a0, const f4v a1, const f4v a2, int id, V3 o, V3 d, float& tbest, int& ibest) {
+    // intersectTriangle (Moller-Trumbore), raytracer_kernel.cu:106-150
+    const V3 v0 = v3(a0.x, a0.y, a0.z), e1 = v3(a1.x, a1.y, a1.z), e2 = v3(a2.x, a2.y, a2.z);
+    const V3 h = cross(d, e2);
+    const float a = dot(e1, h);
+    const float f = rcp(a);
+    const V3 s = o - v0;
+    const float u = f * dot(s, h);
+    const V3 q = cross(s, e1);
+    const float v = f * dot(d, q);
+    const float t = f * dot(e2, q);
+    const bool ok = fabsf(a) >= 1e-8f && u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f &&
+                    t >= RAY_MIN_T && t <= RAY_MAX_T;
+    if (ok && t < tbest) { tbest = t; ibest = id; }
+}
+
 // Closest hit over spheres, planes, triangles in that order with a strict '<'
 // (intersectScene, raytracer_kernel.cu:152-184).  Only (t, primitive id) are tracked; the hit
-// record is built once for the winner.  All scene operands are wave-uniform (SGPR) loads.
+// record is built once for the winner.  The arrays are padded (to 4 spheres, 2 planes, 2
+// triangles) with primitives no ray can hit, so each loop trip fetches a whole batch of
+// operands with one wait and never reads past the arena.
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, float& tbest, int& ibest,
                                             uint32_t& n_roots) {
     tbest = FLT_MAX;  // Scene.cuh:11
     ibest = -1;
-    for (int i = 0; i < sc.ns; ++i) {  // intersectSphere, :44-78
-        const float4 s = sc.sph[i];
-        const V3 oc = v3(o.x - s.x, o.y - s.y, o.z - s.z);
-        const float half_b = dot(oc, d);
-        const float c = dot(oc, oc) - s.w;
-        const float disc = half_b * half_b - c;
-        if (disc >= 0.0f) {
-            if (COUNT) n_roots++;
-            const float sq = fsqrt(disc);
-            float root = -half_b - sq;
-            if (!(root >= RAY_MIN_T && root <= RAY_MAX_T)) root = -half_b + sq;
-            if (root >= RAY_MIN_T && root <= RAY_MAX_T && root < tbest) { tbest = root; ibest = i; }
-        }
+    const cf4 sph = as_const(sc.sph), pl = as_const(sc.pl), tri = as_const(sc.tri);
+    for (int i = 0; i < sc.ns; i += 4) {
+        const f4v s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
+        sphere_test<COUNT>(s0, i, o, d, tbest, ibest, n_roots);
+        sphere_test<COUNT>(s1, i + 1, o, d, tbest, ibest, n_roots);
+        sphere_test<COUNT>(s2, i + 2, o, d, tbest, ibest, n_roots);
+        sphere_test<COUNT>(s3, i + 3, o, d, tbest, ibest, n_roots);
     }
-    for (int i = 0; i < sc.np; ++i) {  // intersectPlane, :80-103
-        const float4 n = sc.pl_n[i];
-        const float4 p = sc.pl_p[i];
-        const float denom = n.x * d.x + n.y * d.y + n.z * d.z;
-        const float num = (p.x - o.x) * n.x + (p.y - o.y) * n.y + (p.z - o.z) * n.z;
-        const float t = num * rcp(denom);
-        if (fabsf(denom) >= 1e-6f && t >= RAY_MIN_T && t <= RAY_MAX_T && t < tbest) { tbest = t; ibest = sc.ns + i; }
+    for (int i = 0; i < sc.np; i += 2) {
+        const f4v n0 = pl[2 * i], p0 = pl[2 * i + 1], n1 = pl[2 * i + 2], p1 = pl[2 * i + 3];
+        plane_test(n0, p0, sc.ns + i, o, d, tbest, ibest);
+        plane_test(n1, p1, sc.ns + i + 1, o, d, tbest, ibest);
     }
-    for (int i = 0; i < sc.nt; ++i) {  // intersectTriangle (Moller-Trumbore), :106-150
-        const V3 v0 = xyz(sc.tri[4 * i + 0]);
-        const V3 e1 = xyz(sc.tri[4 * i + 1]);
-        const V3 e2 = xyz(sc.tri[4 * i + 2]);
-        const V3 h = cross(d, e2);
-        const float a = dot(e1, h);
-        const float f = rcp(a);
-        const V3 s = o - v0;
-        const float u = f * dot(s, h);
-        const V3 q = cross(s, e1);
-        const float v = f * dot(d, q);
-        const float t = f * dot(e2, q);
-        const bool ok = fabsf(a) >= 1e-8f && u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f &&
-                        t >= RAY_MIN_T && t <= RAY_MAX_T;
-        if (ok && t < tbest) { tbest = t; ibest = sc.ns + sc.np + i; }
+    for (int i = 0; i < sc.nt; i += 2) {
+        const f4v a0 = tri[4 * i], a1 = tri[4 * i + 1], a2 = tri[4 * i + 2];
+        const f4v b0 = tri[4 * i + 4], b1 = tri[4 * i + 5], b2 = tri[4 * i + 6];
+        tri_test(a0, a1, a2, sc.ns + sc.np + i, o, d, tbest, ibest);
+        tri_test(b0, b1, b2, sc.ns + sc.np + i + 1, o, d, tbest, ibest);
     }
 }
 
@@ -263,7 +318,7 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
                     n = (p - xyz(s)) * aux.x;
                     mat = __float_as_uint(aux.y);
                 } else if (id < sc.ns + sc.np) {
-                    const float4 q = sc.pl_n[id - sc.ns];
+                    const float4 q = sc.pl[2 * (id - sc.ns)];
                     n = xyz(q); mat = __float_as_uint(q.w);
                 } else {
                     const float4 q = sc.tri[4 * (id - sc.ns - sc.np) + 3];
