@@ -67,6 +67,9 @@ struct PtContext {
     uint64_t* counters = nullptr;  // 12 x u64
     uint32_t* ids = nullptr;       // 2 * npix, allocated on demand
     float* sink = nullptr;
+    uint32_t* work_counter = nullptr;  // tile tickets of the path kernel; never reset, see work_base
+    uint32_t work_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // values the counters have once every enqueued launch has run
+    uint32_t resident_blocks[4] = {0, 0, 0, 0};  // per kernel variant (nee, count)
 };
 
 namespace {
@@ -119,6 +122,13 @@ inline D3h dsub(D3h a, D3h b) { return D3h{a.x - b.x, a.y - b.y, a.z - b.z}; }
 
 inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
+inline uint32_t hash32(uint32_t x) {  // counter-RNG finaliser, DESIGN.md §RNG
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
 }  // namespace
 
 extern "C" {
@@ -142,6 +152,8 @@ int pt_create(int device_id, PtContext** out) {
     e = hipMalloc((void**)&ctx->counters, 12 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMemset(ctx->counters, 0, 12 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->sink, 256);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->work_counter, 1024);
+    if (e == hipSuccess) e = hipMemset(ctx->work_counter, 0, 1024);
     if (e != hipSuccess) { pt_destroy(ctx); return fail(PT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e)); }
     *out = ctx;
     return PT_OK;
@@ -157,6 +169,7 @@ int pt_destroy(PtContext* ctx) {
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->ids) (void)hipFree(ctx->ids);
     if (ctx->sink) (void)hipFree(ctx->sink);
+    if (ctx->work_counter) (void)hipFree(ctx->work_counter);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (g_current == ctx) g_current = nullptr;
     delete ctx;
@@ -212,56 +225,63 @@ int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
     // ---- host staging, one arena: [float4 arrays][u32 arrays][double arrays]
     std::vector<float4> f4;
     auto push4 = [&](float x, float y, float z, float w) { f4.push_back(make_float4(x, y, z, w)); };
+    // loop operands, padded to whole batches with primitives no ray can hit
     const size_t o_sph = f4.size();
     for (uint32_t i = 0; i < ns; ++i) { float r = (float)s->sph_r[i]; push4((float)s->sph_cx[i], (float)s->sph_cy[i], (float)s->sph_cz[i], r * r); }
-    for (uint32_t i = ns; i % 4 != 0 || i == 0; ++i) push4(0, 0, 0, -1.0f);  // padding: r*r < 0 gives disc < 0 for every ray
-    const size_t o_aux = f4.size();
-    for (uint32_t i = 0; i < ns; ++i) {
-        float r = (float)s->sph_r[i];
-        push4(1.0f / r, u2f(s->sph_mat[i]), u2f((uint32_t)sphere_light[i]), u2f(s->sph_emissive[i] ? 1u : 0u));
-    }
-    const size_t o_sem = f4.size();
-    for (uint32_t i = 0; i < ns; ++i) push4((float)s->sph_em_r[i], (float)s->sph_em_g[i], (float)s->sph_em_b[i], 0.f);
+    for (uint32_t i = ns; i % 4 != 0 || i == 0; ++i) push4(0, 0, 0, -1.0f);  // r*r < 0: discriminant < 0 for every ray
     const size_t o_pl = f4.size();
+    std::vector<F3> pl_normal(np);
     for (uint32_t i = 0; i < np; ++i) {  // Plane_t's constructor normalises in float (ImplicitObject.cuh:165)
         F3 n = fnorm(F3{(float)s->pl_nx[i], (float)s->pl_ny[i], (float)s->pl_nz[i]});
-        push4(n.x, n.y, n.z, u2f(s->pl_mat[i]));
-        push4((float)s->pl_px[i], (float)s->pl_py[i], (float)s->pl_pz[i], 0.f);
+        pl_normal[i] = n;
+        const float px = (float)s->pl_px[i], py = (float)s->pl_py[i], pz = (float)s->pl_pz[i];
+        push4(n.x, n.y, n.z, -(px * n.x + py * n.y + pz * n.z));
     }
-    for (uint32_t i = np; i % 2 != 0 || i == 0; ++i) { push4(0, 0, 0, 0); push4(0, 0, 0, 0); }  // padding: denom == 0 never hits
+    for (uint32_t i = np; i % 4 != 0 || i == 0; ++i) push4(0, 0, 0, 0);  // n = 0: |denom| < 1e-6
     const size_t o_tri = f4.size();
+    std::vector<F3> tri_normal(nt);
     for (uint32_t i = 0; i < nt; ++i) {
-        F3 v0{(float)s->tri_v0x[i], (float)s->tri_v0y[i], (float)s->tri_v0z[i]};
-        F3 v1{(float)s->tri_v1x[i], (float)s->tri_v1y[i], (float)s->tri_v1z[i]};
-        F3 v2{(float)s->tri_v2x[i], (float)s->tri_v2y[i], (float)s->tri_v2z[i]};
-        F3 e1{v1.x - v0.x, v1.y - v0.y, v1.z - v0.z}, e2{v2.x - v0.x, v2.y - v0.y, v2.z - v0.z};
-        F3 n = fnorm(fcross(e1, e2));  // Triangle_t::computeNormal, Polygon.cuh:53-57
-        push4(v0.x, v0.y, v0.z, 0.f); push4(e1.x, e1.y, e1.z, 0.f); push4(e2.x, e2.y, e2.z, 0.f);
-        push4(n.x, n.y, n.z, u2f(s->tri_mat[i]));
+        // vertices as the reference holds them (float), the affine map in double
+        const double v0[3] = {(double)(float)s->tri_v0x[i], (double)(float)s->tri_v0y[i], (double)(float)s->tri_v0z[i]};
+        const double v1[3] = {(double)(float)s->tri_v1x[i], (double)(float)s->tri_v1y[i], (double)(float)s->tri_v1z[i]};
+        const double v2[3] = {(double)(float)s->tri_v2x[i], (double)(float)s->tri_v2y[i], (double)(float)s->tri_v2z[i]};
+        D3h e1{v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]}, e2{v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+        D3h n = dcross(e1, e2);
+        const double det = n.x * n.x + n.y * n.y + n.z * n.z;  // e1 . (e2 x n) = |n|^2
+        D3h r0{0, 0, 0}, r1{0, 0, 0}, r2{0, 0, 0};
+        if (det > 0) { r0 = dmul(dcross(e2, n), 1 / det); r1 = dmul(dcross(n, e1), 1 / det); r2 = dmul(n, 1 / det); }
+        auto row = [&](D3h r) { push4((float)r.x, (float)r.y, (float)r.z, (float)-(r.x * v0[0] + r.y * v0[1] + r.z * v0[2])); };
+        row(r0); row(r1); row(r2);
+        F3 fe1{(float)e1.x, (float)e1.y, (float)e1.z}, fe2{(float)e2.x, (float)e2.y, (float)e2.z};
+        tri_normal[i] = fnorm(fcross(fe1, fe2));  // Triangle_t::computeNormal, Polygon.cuh:53-57
     }
-    for (uint32_t i = nt; i % 2 != 0 || i == 0; ++i) for (int k = 0; k < 4; ++k) push4(0, 0, 0, 0);  // padding: a == 0 never hits
-    const size_t o_ma = f4.size();
-    for (uint32_t i = 0; i < nm; ++i) push4((float)s->mat_albedo_r[i], (float)s->mat_albedo_g[i], (float)s->mat_albedo_b[i], u2f(s->mat_type[i]));
-    const size_t o_mb = f4.size();
-    for (uint32_t i = 0; i < nm; ++i) {
-        float rough = (float)s->mat_roughness[i];
-        if (s->mat_type[i] == PT_MAT_METAL) rough = rough < 1.0f ? rough : 1.0f;  // Metal_t ctor, Material.cuh:94
-        push4(rough, (float)s->mat_metallic[i], (float)s->mat_ior[i], 0.f);
+    for (uint32_t i = nt; i % 2 != 0 || i == 0; ++i) for (int k = 0; k < 3; ++k) push4(0, 0, 0, 0);  // zero map: t is NaN
+    // winner records: one 64-B line per primitive
+    const size_t o_rec = f4.size();
+    auto push_material = [&](uint32_t m, int32_t light) {
+        float rough = (float)s->mat_roughness[m];
+        if (s->mat_type[m] == PT_MAT_METAL) rough = rough < 1.0f ? rough : 1.0f;  // Metal_t ctor, Material.cuh:94
+        push4((float)s->mat_albedo_r[m], (float)s->mat_albedo_g[m], (float)s->mat_albedo_b[m], u2f(s->mat_type[m]));
+        push4(rough, (float)s->mat_metallic[m], (float)s->mat_ior[m], u2f((uint32_t)light));
+        push4((float)s->mat_em_r[m], (float)s->mat_em_g[m], (float)s->mat_em_b[m], 0.f);
+    };
+    for (uint32_t i = 0; i < ns; ++i) {
+        push4((float)s->sph_cx[i], (float)s->sph_cy[i], (float)s->sph_cz[i], 1.0f / (float)s->sph_r[i]);
+        push_material(s->sph_mat[i], sphere_light[i]);
     }
-    const size_t o_me = f4.size();
-    for (uint32_t i = 0; i < nm; ++i) push4((float)s->mat_em_r[i], (float)s->mat_em_g[i], (float)s->mat_em_b[i], 0.f);
+    for (uint32_t i = 0; i < np; ++i) { push4(pl_normal[i].x, pl_normal[i].y, pl_normal[i].z, 0.f); push_material(s->pl_mat[i], -1); }
+    for (uint32_t i = 0; i < nt; ++i) { push4(tri_normal[i].x, tri_normal[i].y, tri_normal[i].z, 0.f); push_material(s->tri_mat[i], -1); }
     const size_t o_lt = f4.size();
-    for (uint32_t j = 0; j < nl; ++j) f4.push_back(f4[o_sph + light_sphere[j]]);
-    if (nl == 0) push4(0, 0, 0, 0);
+    for (uint32_t j = 0; j < nl; ++j) {
+        const uint32_t i = light_sphere[j], m = s->sph_mat[i];
+        f4.push_back(f4[o_sph + i]);
+        push4((float)s->mat_em_r[m], (float)s->mat_em_g[m], (float)s->mat_em_b[m], u2f(i));
+        if (s->sph_emissive[i]) push4((float)s->sph_em_r[i], (float)s->sph_em_g[i], (float)s->sph_em_b[i], 0.f);
+        else push4((float)s->mat_em_r[m], (float)s->mat_em_g[m], (float)s->mat_em_b[m], 0.f);
+    }
+    if (nl == 0) for (int k = 0; k < 3; ++k) push4(0, 0, 0, 0);
 
     std::vector<uint32_t> u32;
-    const size_t o_ls = u32.size();
-    for (uint32_t j = 0; j < nl; ++j) u32.push_back(light_sphere[j]);
-    if (nl == 0) u32.push_back(0);
-    const size_t o_obj = u32.size();
-    for (uint32_t i = 0; i < ns; ++i) u32.push_back(s->sph_obj[i]);
-    for (uint32_t i = 0; i < np; ++i) u32.push_back(s->pl_obj[i]);
-    for (uint32_t i = 0; i < nt; ++i) u32.push_back(s->tri_obj[i]);
     const size_t o_si = u32.size();
     for (uint32_t i = 0; i < ns; ++i) { u32.push_back(s->sph_mat[i]); u32.push_back(s->sph_obj[i]); u32.push_back(s->sph_emissive[i] ? 1u : 0u); }
     const size_t o_pi = u32.size();
@@ -307,9 +327,7 @@ int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
     const uint32_t* U = (const uint32_t*)((const unsigned char*)ctx->scene_arena + b_f4);
     const double* D = (const double*)((const unsigned char*)ctx->scene_arena + b_f4 + b_u32);
     DevSceneF& sf = ctx->sf;
-    sf.sph = F + o_sph; sf.sph_aux = F + o_aux; sf.sph_em = F + o_sem; sf.pl = F + o_pl;
-    sf.tri = F + o_tri; sf.mat_a = F + o_ma; sf.mat_b = F + o_mb; sf.mat_e = F + o_me; sf.lights = F + o_lt;
-    sf.light_sphere = U + o_ls; sf.obj_ids = U + o_obj;
+    sf.sph = F + o_sph; sf.pl = F + o_pl; sf.tri = F + o_tri; sf.rec = F + o_rec; sf.lights = F + o_lt;
     sf.ns = (int)ns; sf.np = (int)np; sf.nt = (int)nt; sf.nl = (int)nl;
     DevSceneD& sd = ctx->sd;
     sd.sph = D + o_dsph; sd.pl = D + o_dpl; sd.tri = D + o_dtri; sd.sph_em = D + o_dem; sd.mat_albedo = D + o_dal;
@@ -352,6 +370,7 @@ int pt_set_camera(PtContext* ctx, const PtCamera* c) {
     cf.rx = u.x; cf.ry = u.y; cf.rz = u.z;
     cf.ux = v.x; cf.uy = v.y; cf.uz = v.z;
     cf.half_w = vw * 0.5f; cf.half_h = vh * 0.5f;
+    cf.sx = 2.0f * cf.half_w / (float)c->width; cf.sy = 2.0f * cf.half_h / (float)(int)c->height;
     cf.width = c->width; cf.height = c->height;
 
     DevCamD& cd = ctx->cd;
@@ -433,17 +452,32 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     a.rgba = prm->fused_rgba8 ? (uint32_t*)ctx->display : nullptr;
     a.counters = (prm->flags & PT_FLAG_COUNTERS) ? ctx->counters : nullptr;
     a.s0 = sample_begin; a.count = sample_count;
-    a.max_depth = prm->max_depth; a.rr_depth = prm->rr_depth; a.seed = prm->seed;
+    a.max_depth = prm->max_depth; a.rr_depth = prm->rr_depth; a.seed_hash = hash32(prm->seed);
     a.light_colour = (prm->flags & PT_FLAG_LIGHT_COLOUR) ? 1u : 0u;
     a.acc_mode = prm->acc_mode;
     a.mean_t = 1.0f / (float)(sample_begin + 1u);  // :299
     a.tiles_x = (ctx->width + 7u) / 8u; a.tiles_y = (ctx->height + 7u) / 8u;
     a.num_tiles = a.tiles_x * a.tiles_y;
-    uint32_t tpw;
-    if (prm->pixels_per_wave) tpw = (prm->pixels_per_wave + 63u) / 64u;
-    else tpw = (a.num_tiles + 8191u) / 8192u;  // about one resident wave per slot: 256 CUs x 4 SIMDs x 8
-    a.tiles_per_wave = tpw < 1u ? 1u : (tpw > 1024u ? 1024u : tpw);
-    HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, (prm->flags & PT_FLAG_NEE_MIS) != 0, (prm->flags & PT_FLAG_COUNTERS) != 0, ctx->stream));
+    const bool nee = (prm->flags & PT_FLAG_NEE_MIS) != 0, cnt = (prm->flags & PT_FLAG_COUNTERS) != 0;
+    uint32_t& resident = ctx->resident_blocks[(nee ? 2 : 0) + (cnt ? 1 : 0)];
+    if (resident == 0) HIP_TRY(pt_path_resident_blocks(nee, cnt, ctx->device, &resident));
+    // one ticket = tiles_per_grab 8x8 tiles; default one tile (64 pixels x sample_count paths)
+    uint32_t tpg = prm->pixels_per_wave ? (prm->pixels_per_wave + 63u) / 64u : 1u;
+    a.tiles_per_grab = tpg < 1u ? 1u : (tpg > 4096u ? 4096u : tpg);
+    uint32_t grabs = 0, shard_grabs[8];
+    for (uint32_t sh = 0; sh < 8; ++sh) {
+        const uint32_t tiles = (a.num_tiles + 7u - sh) >> 3;
+        shard_grabs[sh] = (tiles + a.tiles_per_grab - 1u) / a.tiles_per_grab;
+        grabs += shard_grabs[sh];
+    }
+    uint32_t blocks = (grabs + 3u) / 4u;            // no more waves than tickets ...
+    if (blocks > resident) blocks = resident;       // ... and no more than are resident at once
+    if (blocks < 8u) blocks = 8u;                   // every shard needs a block to serve its tiles
+    a.work_counter = ctx->work_counter;
+    for (uint32_t sh = 0; sh < 8; ++sh) a.work_base[sh] = ctx->work_base[sh];
+    HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, blocks, ctx->stream));
+    // shard sh takes exactly shard_grabs[sh] atomics per launch (see the kernel's header comment)
+    for (uint32_t sh = 0; sh < 8; ++sh) ctx->work_base[sh] += shard_grabs[sh];
     ctx->last_acc_mode = prm->acc_mode;
     if (prm->fused_rgba8) ctx->display_bytes = (size_t)ctx->width * ctx->height * 4;
     return PT_OK;

@@ -10,20 +10,19 @@
 #include <stdint.h>
 
 // ---- FP32 scene for the `path` kernel -------------------------------------------------
+// Loop operands (sph, pl, tri) are padded with never-hit primitives to whole batches (4 spheres,
+// 4 planes, 2 triangles) so each loop trip is one s_load_dwordx16 + one wait.
 struct DevSceneF {
-    // Loop operands are padded with never-hit primitives: sph to a multiple of 4, pl and tri to a
-    // multiple of 2 entries, so the intersection loops fetch whole batches (scalar loads).
-    const float4* sph;      // [ns]  cx, cy, cz, r*r            (loop operand, scalar loads)
-    const float4* sph_aux;  // [ns]  1/r, bits(mat), bits(light index | -1), bits(makeEmissive flag)
-    const float4* sph_em;   // [ns]  makeEmissive colour*strength, 0
-    const float4* pl;       // [2*np] unit normal, bits(mat) | point, 0   (loop operand; normal also gathered by the winner)
-    const float4* tri;      // [4*nt] v0 | e1=v1-v0 | e2=v2-v0 | unit normal, bits(mat)
-    const float4* mat_a;    // [nm]  albedo rgb, bits(type)
-    const float4* mat_b;    // [nm]  roughness (clamped for Metal), metallic, ior, 0
-    const float4* mat_e;    // [nm]  emission rgb (colour*strength), 0
-    const float4* lights;   // [nl]  cx, cy, cz, r*r of light j
-    const uint32_t* light_sphere;  // [nl] sphere index of light j
-    const uint32_t* obj_ids;       // [ns+np+nt] insertion index of primitive (spheres, planes, tris)
+    const float4* sph;     // [ns4]    cx, cy, cz, r*r
+    const float4* pl;      // [np4]    unit normal, -(point . normal)
+    const float4* tri;     // [3*nt2]  rows of the world -> (u, v, height) affine map of the triangle
+    const float4* rec;     // [4*(ns+np+nt)] winner record, one 64-B line per primitive:
+                           //   0: sphere (cx,cy,cz,1/r) | plane, triangle (unit normal, 0)
+                           //   1: albedo rgb, bits(material type)
+                           //   2: roughness (clamped for Metal), metallic, ior, bits(light index | -1)
+                           //   3: material emission rgb (colour*strength), 0
+    const float4* lights;  // [3*nl]   (cx,cy,cz,r*r) | (shared-material emission, bits(sphere index))
+                           //          | (makeEmissive colour*strength of that sphere, 0)
     int ns, np, nt, nl;
 };
 
@@ -33,20 +32,23 @@ struct DevCamF {
     float rx, ry, rz;  // right   =  u
     float ux, uy, uz;  // up      =  v
     float half_w, half_h;
+    float sx, sy;      // 2*half_w/width, 2*half_h/height
     uint32_t width, height;
 };
 
 struct PathArgs {
     float4* accum;
-    uint32_t* rgba;       // display buffer (fused resolve) or nullptr
-    uint64_t* counters;   // 12 x u64 (PtCounters order) or nullptr
-    uint32_t s0, count;   // sample range of this launch
-    uint32_t max_depth, rr_depth, seed;
-    uint32_t light_colour;      // PT_FLAG_LIGHT_COLOUR
-    uint32_t acc_mode;          // PT_ACC_*
-    float mean_t;               // 1/(s0+1) for PT_ACC_RUNNING_MEAN
+    uint32_t* rgba;          // display buffer (fused resolve) or nullptr
+    uint64_t* counters;      // 12 x u64 (PtCounters order) or nullptr
+    uint32_t* work_counter;  // 8 ticket counters on separate 128-B lines (word 32*s), never reset
+    uint32_t work_base[8];   // their values when this launch starts
+    uint32_t s0, count;      // sample range of this launch
+    uint32_t max_depth, rr_depth, seed_hash;
+    uint32_t light_colour;   // PT_FLAG_LIGHT_COLOUR
+    uint32_t acc_mode;       // PT_ACC_*
+    float mean_t;            // 1/(s0+1) for PT_ACC_RUNNING_MEAN
     uint32_t tiles_x, tiles_y;  // 8x8 pixel tiles
-    uint32_t tiles_per_wave;
+    uint32_t tiles_per_grab;
     uint32_t num_tiles;
 };
 
@@ -75,7 +77,9 @@ struct DevCamD {
 
 // ---- launchers implemented in the .hip translation units ------------------------------
 hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArgs& a, bool nee, bool count,
-                          hipStream_t stream);
+                          uint32_t blocks, hipStream_t stream);
+// Resident 256-thread blocks per CU of each path-kernel variant (occupancy query) x CU count.
+hipError_t pt_path_resident_blocks(bool nee, bool count, int device, uint32_t* blocks);
 hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint32_t acc_mode, uint32_t mode,
                              hipStream_t stream);
 hipError_t pt_launch_valu_peak(float* sink, uint32_t packed, uint32_t iters, uint32_t blocks, hipStream_t stream);

