@@ -476,8 +476,8 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     a.work_counter = ctx->work_counter;
     for (uint32_t sh = 0; sh < 8; ++sh) a.work_base[sh] = ctx->work_base[sh];
     HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, blocks, ctx->stream));
-    // shard sh takes exactly shard_grabs[sh] atomics per launch (see the kernel's header comment)
-    for (uint32_t sh = 0; sh < 8; ++sh) ctx->work_base[sh] += shard_grabs[sh];
+    // shard sh takes exactly T + n atomics per launch: its tickets plus one failing draw per wave
+    for (uint32_t sh = 0; sh < 8; ++sh) ctx->work_base[sh] += shard_grabs[sh] + ((blocks + 7u - sh) >> 3) * 4u;
     ctx->last_acc_mode = prm->acc_mode;
     if (prm->fused_rgba8) ctx->display_bytes = (size_t)ctx->width * ctx->height * 4;
     return PT_OK;

@@ -194,26 +194,25 @@ __device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
 }
 
 // The grid is exactly the set of waves that is resident at once (occupancy x CUs).  Every wave
-// works through tickets: a ticket is a batch of 8x8 pixel tiles.  Its first ticket is its own
-// index (no atomic); afterwards it draws tickets from a global counter until the frame is
+// draws tickets (a ticket is a batch of 8x8 pixel tiles) from a global counter until the frame is
 // exhausted, so no wave slot idles while tiles are still queued (a static split loses up to a
-// whole scheduling round to quantisation: 8100 waves on 7168 slots).  One counter word sustains
+// whole scheduling round to quantisation: 8100 waves on 7168 slots).  No ticket is ever owned
+// implicitly: a block that the hardware admits late (the occupancy query can be one block per
+// CU high, MI355X_MICROARCH.md §Residency) must not hold tiles hostage until the end.  One counter word sustains
 // only ~88 returning atomics per microsecond chip-wide (MI355X_MICROARCH.md, row `dequeue`),
 // which a 720p frame (14 400 tiles) would saturate, so the counter is sharded 8 ways on separate
 // 128-B lines: shard = blockIdx % 8 (blocks b and b+8 share an XCD under round-robin dispatch)
 // serves the tiles congruent to it mod 8.  Counters are never reset: a launch draws exactly
-// T_s = ceil(tiles_s / tiles_per_grab) atomics from shard s (max(0, T_s - n_s) useful ones plus
-// one failing draw per working wave), so the host passes each counter's starting value.
+// T_s + n_s atomics from shard s (T_s = ceil(tiles_s / tiles_per_grab) useful ones plus one failing
+// draw for each of its n_s waves), so the host passes each counter's starting value.
 template <bool NEE, bool COUNT>
 __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const DevCamF cam, const PathArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t shard = blockIdx.x & 7u;
-    const uint32_t wave_in_shard = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6);
-    const uint32_t waves_in_shard = ((gridDim.x + 7u - shard) >> 3) * 4u;
     const uint32_t shard_tiles = (a.num_tiles + 7u - shard) >> 3;  // tiles with index = shard (mod 8)
     const uint32_t shard_grabs = (shard_tiles + a.tiles_per_grab - 1u) / a.tiles_per_grab;
     uint32_t tile0 = 0, pool_size = 0, pool_next = 0;  // wave-uniform; tile0 counts within the shard
-    bool exhausted = false, first = true;               // wave-uniform
+    bool exhausted = false;                             // wave-uniform
 
     // lane state
     int my = -1;             // pool index of the pixel this lane owns, -1 = none
@@ -263,12 +262,9 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
         const uint64_t want_mask = __ballot(want);
         if (want_mask != 0ull && !exhausted) {
             if (pool_next >= pool_size) {
-                uint32_t ticket = wave_in_shard;
-                if (!first) {
-                    if (lane == 0) ticket = atomicAdd(a.work_counter + shard * 32u, 1u) - a.work_base[shard] + waves_in_shard;
-                    ticket = __builtin_amdgcn_readfirstlane(ticket);
-                }
-                first = false;
+                uint32_t ticket = 0;
+                if (lane == 0) ticket = atomicAdd(a.work_counter + shard * 32u, 1u) - a.work_base[shard];
+                ticket = __builtin_amdgcn_readfirstlane(ticket);
                 if (ticket >= shard_grabs) {
                     exhausted = true;
                 } else {
