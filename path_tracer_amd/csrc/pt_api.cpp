@@ -68,7 +68,7 @@ struct PtContext {
     uint32_t* ids = nullptr;       // 2 * npix, allocated on demand
     float* sink = nullptr;
     uint32_t* work_counter = nullptr;  // tile tickets of the path kernel; never reset, see work_base
-    uint32_t work_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // values the counters have once every enqueued launch has run
+    uint32_t work_parity = 0;          // which of the two counter sets the next launch uses
     uint32_t resident_blocks[4] = {0, 0, 0, 0};  // per kernel variant (nee, count)
 };
 
@@ -152,8 +152,8 @@ int pt_create(int device_id, PtContext** out) {
     e = hipMalloc((void**)&ctx->counters, 12 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMemset(ctx->counters, 0, 12 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->sink, 256);
-    if (e == hipSuccess) e = hipMalloc((void**)&ctx->work_counter, 1024);
-    if (e == hipSuccess) e = hipMemset(ctx->work_counter, 0, 1024);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->work_counter, 2048);
+    if (e == hipSuccess) e = hipMemset(ctx->work_counter, 0, 2048);
     if (e != hipSuccess) { pt_destroy(ctx); return fail(PT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e)); }
     *out = ctx;
     return PT_OK;
@@ -461,23 +461,22 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     const bool nee = (prm->flags & PT_FLAG_NEE_MIS) != 0, cnt = (prm->flags & PT_FLAG_COUNTERS) != 0;
     uint32_t& resident = ctx->resident_blocks[(nee ? 2 : 0) + (cnt ? 1 : 0)];
     if (resident == 0) HIP_TRY(pt_path_resident_blocks(nee, cnt, ctx->device, &resident));
-    // one ticket = tiles_per_grab 8x8 tiles; default one tile (64 pixels x sample_count paths)
-    uint32_t tpg = prm->pixels_per_wave ? (prm->pixels_per_wave + 63u) / 64u : 1u;
-    a.tiles_per_grab = tpg < 1u ? 1u : (tpg > 4096u ? 4096u : tpg);
-    uint32_t grabs = 0, shard_grabs[8];
-    for (uint32_t sh = 0; sh < 8; ++sh) {
-        const uint32_t tiles = (a.num_tiles + 7u - sh) >> 3;
-        shard_grabs[sh] = (tiles + a.tiles_per_grab - 1u) / a.tiles_per_grab;
-        grabs += shard_grabs[sh];
-    }
-    uint32_t blocks = (grabs + 3u) / 4u;            // no more waves than tickets ...
-    if (blocks > resident) blocks = resident;       // ... and no more than are resident at once
-    if (blocks < 8u) blocks = 8u;                   // every shard needs a block to serve its tiles
-    a.work_counter = ctx->work_counter;
-    for (uint32_t sh = 0; sh < 8; ++sh) a.work_base[sh] = ctx->work_base[sh];
+    a.inv_tiles_x = 1.0f / (float)a.tiles_x;
+    a.total_w = (float)(sample_begin + sample_count); a.inv_total_w = 1.0f / a.total_w;
+    // work unit = 4x4 pixels; a ticket is at least units_per_grab of them.  Default: aim at >= 8
+    // tickets per resident wave, but never more than one 8x8 tile per ticket.
+    const uint32_t units = a.num_tiles * 4u;
+    uint32_t upg;
+    if (prm->pixels_per_wave) upg = (prm->pixels_per_wave + 15u) / 16u;
+    else { upg = units / (resident * 4u * 8u); upg = upg > 4u ? 4u : upg; }
+    a.units_per_grab = upg < 1u ? 1u : (upg > 65536u ? 65536u : upg);
+    uint32_t blocks = (units / a.units_per_grab + 3u) / 4u;  // no more waves than tickets ...
+    if (blocks > resident) blocks = resident;                // ... and no more than are resident at once
+    if (blocks < 8u) blocks = 8u;                            // every shard needs a block to serve its tiles
+    a.work_counter = ctx->work_counter + 256u * ctx->work_parity;
+    a.next_counter = ctx->work_counter + 256u * (ctx->work_parity ^ 1u);
     HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, blocks, ctx->stream));
-    // shard sh takes exactly T + n atomics per launch: its tickets plus one failing draw per wave
-    for (uint32_t sh = 0; sh < 8; ++sh) ctx->work_base[sh] += shard_grabs[sh] + ((blocks + 7u - sh) >> 3) * 4u;
+    ctx->work_parity ^= 1u;
     ctx->last_acc_mode = prm->acc_mode;
     if (prm->fused_rgba8) ctx->display_bytes = (size_t)ctx->width * ctx->height * 4;
     return PT_OK;

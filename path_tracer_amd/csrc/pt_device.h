@@ -40,15 +40,17 @@ struct PathArgs {
     float4* accum;
     uint32_t* rgba;          // display buffer (fused resolve) or nullptr
     uint64_t* counters;      // 12 x u64 (PtCounters order) or nullptr
-    uint32_t* work_counter;  // 8 ticket counters on separate 128-B lines (word 32*s), never reset
-    uint32_t work_base[8];   // their values when this launch starts
+    uint32_t* work_counter;  // this launch's 8 ticket counters on separate 128-B lines (word 32*s), zero at start
+    uint32_t* next_counter;  // the other set: zeroed by this launch for the next one
+    float total_w, inv_total_w;  // (float)(s0 + count) and its reciprocal, for the fused display pack
     uint32_t s0, count;      // sample range of this launch
     uint32_t max_depth, rr_depth, seed_hash;
     uint32_t light_colour;   // PT_FLAG_LIGHT_COLOUR
     uint32_t acc_mode;       // PT_ACC_*
     float mean_t;            // 1/(s0+1) for PT_ACC_RUNNING_MEAN
     uint32_t tiles_x, tiles_y;  // 8x8 pixel tiles
-    uint32_t tiles_per_grab;
+    float inv_tiles_x;
+    uint32_t units_per_grab;    // minimum 4x4-pixel units per ticket
     uint32_t num_tiles;
 };
 

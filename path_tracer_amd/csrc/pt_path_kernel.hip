@@ -149,23 +149,24 @@ __device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, flo
     const cf4 sph = as_const(sc.sph), pl = as_const(sc.pl), tri = as_const(sc.tri);
     for (int i = 0; i < sc.ns; i += 4) {
         const f4v s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
+        // the guards are wave-uniform scalar branches: a padding entry costs no vector work
         sphere_test<COUNT>(s0, i, o, d, tbest, ibest, n_roots);
-        sphere_test<COUNT>(s1, i + 1, o, d, tbest, ibest, n_roots);
-        sphere_test<COUNT>(s2, i + 2, o, d, tbest, ibest, n_roots);
-        sphere_test<COUNT>(s3, i + 3, o, d, tbest, ibest, n_roots);
+        if (i + 1 < sc.ns) sphere_test<COUNT>(s1, i + 1, o, d, tbest, ibest, n_roots);
+        if (i + 2 < sc.ns) sphere_test<COUNT>(s2, i + 2, o, d, tbest, ibest, n_roots);
+        if (i + 3 < sc.ns) sphere_test<COUNT>(s3, i + 3, o, d, tbest, ibest, n_roots);
     }
     for (int i = 0; i < sc.np; i += 4) {
         const f4v p0 = pl[i], p1 = pl[i + 1], p2 = pl[i + 2], p3 = pl[i + 3];
         plane_test(p0, sc.ns + i, o, d, tbest, ibest);
-        plane_test(p1, sc.ns + i + 1, o, d, tbest, ibest);
-        plane_test(p2, sc.ns + i + 2, o, d, tbest, ibest);
-        plane_test(p3, sc.ns + i + 3, o, d, tbest, ibest);
+        if (i + 1 < sc.np) plane_test(p1, sc.ns + i + 1, o, d, tbest, ibest);
+        if (i + 2 < sc.np) plane_test(p2, sc.ns + i + 2, o, d, tbest, ibest);
+        if (i + 3 < sc.np) plane_test(p3, sc.ns + i + 3, o, d, tbest, ibest);
     }
     for (int i = 0; i < sc.nt; i += 2) {
         const f4v a0 = tri[3 * i], a1 = tri[3 * i + 1], a2 = tri[3 * i + 2];
         const f4v b0 = tri[3 * i + 3], b1 = tri[3 * i + 4], b2 = tri[3 * i + 5];
         tri_test(a0, a1, a2, sc.ns + sc.np + i, o, d, tbest, ibest);
-        tri_test(b0, b1, b2, sc.ns + sc.np + i + 1, o, d, tbest, ibest);
+        if (i + 1 < sc.nt) tri_test(b0, b1, b2, sc.ns + sc.np + i + 1, o, d, tbest, ibest);
     }
 }
 
@@ -194,25 +195,27 @@ __device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
 }
 
 // The grid is exactly the set of waves that is resident at once (occupancy x CUs).  Every wave
-// draws tickets (a ticket is a batch of 8x8 pixel tiles) from a global counter until the frame is
-// exhausted, so no wave slot idles while tiles are still queued (a static split loses up to a
-// whole scheduling round to quantisation: 8100 waves on 7168 slots).  No ticket is ever owned
-// implicitly: a block that the hardware admits late (the occupancy query can be one block per
-// CU high, MI355X_MICROARCH.md §Residency) must not hold tiles hostage until the end.  One counter word sustains
-// only ~88 returning atomics per microsecond chip-wide (MI355X_MICROARCH.md, row `dequeue`),
-// which a 720p frame (14 400 tiles) would saturate, so the counter is sharded 8 ways on separate
-// 128-B lines: shard = blockIdx % 8 (blocks b and b+8 share an XCD under round-robin dispatch)
-// serves the tiles congruent to it mod 8.  Counters are never reset: a launch draws exactly
-// T_s + n_s atomics from shard s (T_s = ceil(tiles_s / tiles_per_grab) useful ones plus one failing
-// draw for each of its n_s waves), so the host passes each counter's starting value.
+// draws work from a global ticket counter until the frame is exhausted, so no wave slot idles
+// while pixels are still queued (a static split loses up to a whole scheduling round to
+// quantisation: 8100 waves on 7168 slots).  The unit of work is a 4x4 pixel block (16 lanes'
+// worth): a wave whose pool is empty draws as many units as it has idle lanes (at least
+// units_per_grab), so tickets stay fine-grained when a pixel carries many samples and a wave
+// still fills all 64 lanes with one atomic when it carries one.  No unit is ever owned
+// implicitly: a block that the hardware admits late (the occupancy query can be one block per CU
+// high, MI355X_MICROARCH.md §Residency) must not hold pixels hostage until the end.
+// One counter word sustains only ~88 returning atomics per microsecond chip-wide
+// (MI355X_MICROARCH.md, row `dequeue`), so the counter is sharded 8 ways on separate 128-B
+// lines: shard = blockIdx % 8 (blocks b and b+8 share an XCD under round-robin dispatch) serves
+// the 8x8 tiles congruent to it mod 8.  Two counter sets alternate between launches; each launch
+// zeroes the set of the next one (ordered by the kernel boundary), so no memset is enqueued.
 template <bool NEE, bool COUNT>
 __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const DevCamF cam, const PathArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t shard = blockIdx.x & 7u;
-    const uint32_t shard_tiles = (a.num_tiles + 7u - shard) >> 3;  // tiles with index = shard (mod 8)
-    const uint32_t shard_grabs = (shard_tiles + a.tiles_per_grab - 1u) / a.tiles_per_grab;
-    uint32_t tile0 = 0, pool_size = 0, pool_next = 0;  // wave-uniform; tile0 counts within the shard
+    const uint32_t shard_units = ((a.num_tiles + 7u - shard) >> 3) * 4u;  // 4x4 blocks of the tiles = shard (mod 8)
+    uint32_t unit0 = 0, pool_size = 0, pool_next = 0;  // wave-uniform; unit0 counts within the shard
     bool exhausted = false;                             // wave-uniform
+    if (blockIdx.x == 0 && threadIdx.x < 8u) a.next_counter[threadIdx.x * 32u] = 0u;
 
     // lane state
     int my = -1;             // pool index of the pixel this lane owns, -1 = none
@@ -251,7 +254,8 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
             }
             a.accum[pixel] = acc;
             if (a.rgba) {  // fused convertToRGBAKernel
-                const float inv = (a.acc_mode == 0u) ? 1.0f / acc.w : 1.0f;
+                // every pixel normally holds the same count: its reciprocal comes from the host (same IEEE divide)
+                const float inv = (a.acc_mode != 0u) ? 1.0f : (acc.w == a.total_w ? a.inv_total_w : 1.0f / acc.w);
                 a.rgba[pixel] = pack_rgba8_cuda(acc.x * inv, acc.y * inv, acc.z * inv);
             }
             my = -1;
@@ -262,24 +266,30 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
         const uint64_t want_mask = __ballot(want);
         if (want_mask != 0ull && !exhausted) {
             if (pool_next >= pool_size) {
+                const uint32_t need = max(a.units_per_grab, ((uint32_t)__popcll(want_mask) + 15u) >> 4);
                 uint32_t ticket = 0;
-                if (lane == 0) ticket = atomicAdd(a.work_counter + shard * 32u, 1u) - a.work_base[shard];
+                if (lane == 0) ticket = atomicAdd(a.work_counter + shard * 32u, need);
                 ticket = __builtin_amdgcn_readfirstlane(ticket);
-                if (ticket >= shard_grabs) {
+                if (ticket >= shard_units) {
                     exhausted = true;
                 } else {
-                    tile0 = ticket * a.tiles_per_grab;
-                    pool_size = min(a.tiles_per_grab, shard_tiles - tile0) * 64u;
+                    unit0 = ticket;
+                    pool_size = min(need, shard_units - ticket) * 16u;
                     pool_next = 0;
                 }
             }
             if (!exhausted) {
                 const uint32_t cand = pool_next + lane_prefix(want_mask);
                 if (want && cand < pool_size) {
-                    const uint32_t tile = (tile0 + (cand >> 6)) * 8u + shard, li = cand & 63u;
-                    const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-                    px = tx * 8u + (li & 7u);
-                    py = ty * 8u + (li >> 3);
+                    const uint32_t unit = unit0 + (cand >> 4), li = cand & 15u, q = unit & 3u;
+                    const uint32_t tile = (unit >> 2) * 8u + shard;
+                    // tile / tiles_x without the 25-instruction integer division: float quotient + one fix-up
+                    uint32_t ty = (uint32_t)(((float)tile + 0.5f) * a.inv_tiles_x);
+                    int tx = (int)(tile - ty * a.tiles_x);
+                    if (tx < 0) { tx += (int)a.tiles_x; ty--; }
+                    if (tx >= (int)a.tiles_x) { tx -= (int)a.tiles_x; ty++; }
+                    px = (uint32_t)tx * 8u + (q & 1u) * 4u + (li & 3u);
+                    py = ty * 8u + (q >> 1) * 4u + (li >> 2);
                     if (px < cam.width && py < cam.height) {
                         my = (int)cand;
                         pixel = py * cam.width + px;
