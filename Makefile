@@ -44,7 +44,7 @@ tools/pt_headless: tools/pt_headless.cpp include/pt_host.hpp include/pt.h $(LIB)
 
 isa: $(CSRC)/pt_path_kernel.hip $(CSRC)/pt_device.h
 	@mkdir -p build/isa
-	$(HIPCC) $(HIPFLAGS) -save-temps=obj -Rpass-analysis=kernel-resource-usage -c $(CSRC)/pt_path_kernel.hip -o build/isa/pt_path_kernel.o 2> build/isa/resource_usage.txt || true
+	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -save-temps=obj -Rpass-analysis=kernel-resource-usage -c $(CSRC)/pt_path_kernel.hip -o build/isa/pt_path_kernel.o 2> build/isa/resource_usage.txt || true
 
 clean:
 	rm -rf build $(LIB) tools/pt_headless

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #ifndef M_PI
@@ -229,15 +230,39 @@ int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
     const size_t o_sph = f4.size();
     for (uint32_t i = 0; i < ns; ++i) { float r = (float)s->sph_r[i]; push4((float)s->sph_cx[i], (float)s->sph_cy[i], (float)s->sph_cz[i], r * r); }
     for (uint32_t i = ns; i % 4 != 0 || i == 0; ++i) push4(0, 0, 0, -1.0f);  // r*r < 0: discriminant < 0 for every ray
-    const size_t o_pl = f4.size();
+    // planes: the unit normal is +-e_k for most (every wall of the Cornell boxes); those go to
+    // per-axis lists with the cheap test, the others to the general list.  Ids stay insertion order.
     std::vector<F3> pl_normal(np);
+    std::vector<std::pair<float, uint32_t>> axis_list[3];
+    std::vector<uint32_t> general;
     for (uint32_t i = 0; i < np; ++i) {  // Plane_t's constructor normalises in float (ImplicitObject.cuh:165)
         F3 n = fnorm(F3{(float)s->pl_nx[i], (float)s->pl_ny[i], (float)s->pl_nz[i]});
         pl_normal[i] = n;
+        const float p[3] = {(float)s->pl_px[i], (float)s->pl_py[i], (float)s->pl_pz[i]};
+        const float nn[3] = {n.x, n.y, n.z};
+        const int zeros = (n.x == 0.0f) + (n.y == 0.0f) + (n.z == 0.0f);
+        if (zeros == 2) { const int k = n.x != 0.0f ? 0 : (n.y != 0.0f ? 1 : 2); (void)nn; axis_list[k].push_back({p[k], ns + i}); }
+        else if (zeros < 2) general.push_back(i);
+        // zeros == 3: a degenerate normal can never be hit (|denom| < 1e-6) and is dropped
+    }
+    const size_t o_pl = f4.size();
+    for (uint32_t i : general) {
+        const F3 n = pl_normal[i];
         const float px = (float)s->pl_px[i], py = (float)s->pl_py[i], pz = (float)s->pl_pz[i];
         push4(n.x, n.y, n.z, -(px * n.x + py * n.y + pz * n.z));
+        push4(u2f(ns + i), 0, 0, 0);
     }
-    for (uint32_t i = np; i % 4 != 0 || i == 0; ++i) push4(0, 0, 0, 0);  // n = 0: |denom| < 1e-6
+    for (size_t i = general.size(); i % 4 != 0 || i == 0; ++i) { push4(NAN, NAN, NAN, 0); push4(0, 0, 0, 0); }  // never hit
+    const size_t o_axp = f4.size();
+    size_t ax_off[3];
+    for (int k = 0; k < 3; ++k) {
+        ax_off[k] = f4.size() - o_axp;
+        const auto& L = axis_list[k];
+        for (size_t i = 0; i < L.size() || i == 0; i += 2) {
+            const bool a = i < L.size(), b = i + 1 < L.size();
+            push4(a ? L[i].first : NAN, u2f(a ? L[i].second : 0u), b ? L[i + 1].first : NAN, u2f(b ? L[i + 1].second : 0u));
+        }
+    }
     const size_t o_tri = f4.size();
     std::vector<F3> tri_normal(nt);
     for (uint32_t i = 0; i < nt; ++i) {
@@ -327,8 +352,11 @@ int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
     const uint32_t* U = (const uint32_t*)((const unsigned char*)ctx->scene_arena + b_f4);
     const double* D = (const double*)((const unsigned char*)ctx->scene_arena + b_f4 + b_u32);
     DevSceneF& sf = ctx->sf;
-    sf.sph = F + o_sph; sf.pl = F + o_pl; sf.tri = F + o_tri; sf.rec = F + o_rec; sf.lights = F + o_lt;
+    sf.sph = F + o_sph; sf.pl = F + o_pl; sf.axp = F + o_axp; sf.tri = F + o_tri; sf.rec = F + o_rec; sf.lights = F + o_lt;
     sf.ns = (int)ns; sf.np = (int)np; sf.nt = (int)nt; sf.nl = (int)nl;
+    sf.npg = (int)general.size();
+    sf.nax = (int)axis_list[0].size(); sf.nay = (int)axis_list[1].size(); sf.naz = (int)axis_list[2].size();
+    sf.ax_off_y = (int)ax_off[1]; sf.ax_off_z = (int)ax_off[2];
     DevSceneD& sd = ctx->sd;
     sd.sph = D + o_dsph; sd.pl = D + o_dpl; sd.tri = D + o_dtri; sd.sph_em = D + o_dem; sd.mat_albedo = D + o_dal;
     sd.sph_info = U + o_si; sd.pl_info = U + o_pi; sd.tri_info = U + o_ti;

@@ -14,7 +14,9 @@
 // 4 planes, 2 triangles) so each loop trip is one s_load_dwordx16 + one wait.
 struct DevSceneF {
     const float4* sph;     // [ns4]    cx, cy, cz, r*r
-    const float4* pl;      // [np4]    unit normal, -(point . normal)
+    const float4* pl;      // [2*npg4] general planes: (unit normal, -(point . normal)) | (bits(primitive id), 0, 0, 0)
+    const float4* axp;     // axis-aligned planes, one list per axis (x | y | z), two planes per float4:
+                           //          p_k, bits(primitive id), p_k, bits(primitive id); NaN-padded
     const float4* tri;     // [3*nt2]  rows of the world -> (u, v, height) affine map of the triangle
     const float4* rec;     // [4*(ns+np+nt)] winner record, one 64-B line per primitive:
                            //   0: sphere (cx,cy,cz,1/r) | plane, triangle (unit normal, 0)
@@ -23,7 +25,10 @@ struct DevSceneF {
                            //   3: material emission rgb (colour*strength), 0
     const float4* lights;  // [3*nl]   (cx,cy,cz,r*r) | (shared-material emission, bits(sphere index))
                            //          | (makeEmissive colour*strength of that sphere, 0)
-    int ns, np, nt, nl;
+    int ns, np, nt, nl;     // np = all planes (primitive ids ns .. ns+np-1 in insertion order)
+    int npg;                // general planes
+    int nax, nay, naz;      // axis-aligned planes per axis
+    int ax_off_y, ax_off_z; // float4 offsets of the y and z lists inside axp
 };
 
 struct DevCamF {

@@ -25,6 +25,12 @@
 
 #include <float.h>
 
+// Lanes that must have ended their path before the regeneration steps are entered.  Measured on
+// the MI355X (profiles/r1_variants2.json): 1 (every trip) is fastest; 8/16/24/32 lose 1-12 %.
+#ifndef PT_REGEN_MIN
+#define PT_REGEN_MIN 1u
+#endif
+
 namespace {
 
 constexpr uint32_t MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_EMISSIVE = 4;  // 3 = Glossy (the else branch)
@@ -96,6 +102,11 @@ __device__ __forceinline__ cf4 as_const(const float4* p) {
 // `t < tbest` implies `t <= 1e4` and one compare per primitive disappears.
 constexpr float T_BEST_INIT = 10000.0009765625f;
 
+// Primitive id stored as float bits.  The argument is taken BY VALUE on purpose: hipcc 7.2 reads
+// element 0 of the vector when __builtin_bit_cast is applied directly to an ext_vector element
+// (`__builtin_bit_cast(uint32_t, e.y)` returned the bits of e.x).
+__device__ __forceinline__ int as_id(float f) { return (int)__float_as_uint(f); }
+
 template <bool COUNT>
 __device__ __forceinline__ void sphere_test(const f4v s, int i, V3 o, V3 d, float& tbest, int& ibest, uint32_t& n_roots) {
     // intersectSphere, raytracer_kernel.cu:44-78.  Most rays miss most spheres: the root block is
@@ -114,13 +125,27 @@ __device__ __forceinline__ void sphere_test(const f4v s, int i, V3 o, V3 d, floa
     }
 }
 
+// intersectPlane, raytracer_kernel.cu:80-103, general plane: pn = (unit normal, -(p.n));
+// dot(p - o, n) is expanded to p.n - o.n, so t = -(o.n + w) / (n.d).
 __device__ __forceinline__ void plane_test(const f4v pn, int id, V3 o, V3 d, float& tbest, int& ibest) {
-    // intersectPlane, raytracer_kernel.cu:80-103, with dot(p - o, n) expanded to p.n - o.n and
-    // p.n precomputed: t = -(o.n - p.n) / (n.d)
     const float denom = pn.x * d.x + pn.y * d.y + pn.z * d.z;
     const float q = pn.x * o.x + pn.y * o.y + pn.z * o.z + pn.w;
     const float t = q * rcp(-denom);
     if (fabsf(denom) >= 1e-6f && t >= RAY_MIN_T && t < tbest) { tbest = t; ibest = id; }
+}
+
+// The same test for planes whose unit normal is +-e_k (every wall of the Cornell boxes): n.d =
+// +-d_k and (p - o).n = +-(p_k - o_k), the signs cancel and t = (p_k - o_k) / d_k, with 1/d_k shared
+// by all such planes of the ray (NaN where the reference rejects |n.d| < 1e-6).  Each axis has its
+// own list (two planes per float4: p_k, bits(id), p_k, bits(id); NaN-padded), so the choice of
+// form is made at upload, not by a branch chain in the loop.
+__device__ __forceinline__ void axis_planes(cf4 list, int n, float o_k, float inv_dk, float& tbest, int& ibest) {
+    for (int i = 0; i < n; i += 2) {
+        const f4v e = list[i >> 1];
+        const float t0 = (e.x - o_k) * inv_dk, t1 = (e.z - o_k) * inv_dk;
+        if (t0 >= RAY_MIN_T && t0 < tbest) { tbest = t0; ibest = as_id(e.y); }
+        if (t1 >= RAY_MIN_T && t1 < tbest) { tbest = t1; ibest = as_id(e.w); }
+    }
 }
 
 __device__ __forceinline__ void tri_test(const f4v r0, const f4v r1, const f4v r2, int id, V3 o, V3 d, float& tbest, int& ibest) {
@@ -147,6 +172,9 @@ __device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, flo
     tbest = T_BEST_INIT;
     ibest = -1;
     const cf4 sph = as_const(sc.sph), pl = as_const(sc.pl), tri = as_const(sc.tri);
+    const float qnan = __builtin_nanf("");
+    const V3 inv_d = v3(fabsf(d.x) >= 1e-6f ? rcp(d.x) : qnan, fabsf(d.y) >= 1e-6f ? rcp(d.y) : qnan,
+                        fabsf(d.z) >= 1e-6f ? rcp(d.z) : qnan);
     for (int i = 0; i < sc.ns; i += 4) {
         const f4v s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
         // the guards are wave-uniform scalar branches: a padding entry costs no vector work
@@ -155,12 +183,16 @@ __device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, flo
         if (i + 2 < sc.ns) sphere_test<COUNT>(s2, i + 2, o, d, tbest, ibest, n_roots);
         if (i + 3 < sc.ns) sphere_test<COUNT>(s3, i + 3, o, d, tbest, ibest, n_roots);
     }
-    for (int i = 0; i < sc.np; i += 4) {
-        const f4v p0 = pl[i], p1 = pl[i + 1], p2 = pl[i + 2], p3 = pl[i + 3];
-        plane_test(p0, sc.ns + i, o, d, tbest, ibest);
-        if (i + 1 < sc.np) plane_test(p1, sc.ns + i + 1, o, d, tbest, ibest);
-        if (i + 2 < sc.np) plane_test(p2, sc.ns + i + 2, o, d, tbest, ibest);
-        if (i + 3 < sc.np) plane_test(p3, sc.ns + i + 3, o, d, tbest, ibest);
+    axis_planes(as_const(sc.axp), sc.nax, o.x, inv_d.x, tbest, ibest);
+    axis_planes(as_const(sc.axp) + sc.ax_off_y, sc.nay, o.y, inv_d.y, tbest, ibest);
+    axis_planes(as_const(sc.axp) + sc.ax_off_z, sc.naz, o.z, inv_d.z, tbest, ibest);
+    for (int i = 0; i < sc.npg; i += 4) {
+        const f4v p0 = pl[2 * i], p1 = pl[2 * i + 2], p2 = pl[2 * i + 4], p3 = pl[2 * i + 6];
+        const f4v q0 = pl[2 * i + 1], q1 = pl[2 * i + 3], q2 = pl[2 * i + 5], q3 = pl[2 * i + 7];  // .x = bits(id)
+        plane_test(p0, as_id(q0.x), o, d, tbest, ibest);
+        if (i + 1 < sc.npg) plane_test(p1, as_id(q1.x), o, d, tbest, ibest);
+        if (i + 2 < sc.npg) plane_test(p2, as_id(q2.x), o, d, tbest, ibest);
+        if (i + 3 < sc.npg) plane_test(p3, as_id(q3.x), o, d, tbest, ibest);
     }
     for (int i = 0; i < sc.nt; i += 2) {
         const f4v a0 = tri[3 * i], a1 = tri[3 * i + 1], a2 = tri[3 * i + 2];
@@ -237,6 +269,14 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
     const bool need_prev = a.acc_mode == 0u || a.s0 > 0u;
 
     for (;;) {
+        // Steps (1)-(3) run at the few lanes whose path just ended; executed on every trip they
+        // cost as many instructions as a third of an intersection at ~15 % lane occupancy.  They
+        // are therefore entered only when PT_REGEN_MIN lanes have something to do there (or no
+        // lane is tracing), which trades a few idle lane-trips for fewer low-occupancy instructions.
+        const bool todo = !alive && (my >= 0 || !exhausted);
+        const uint64_t todo_mask = __ballot(todo);
+        const bool regen = (uint32_t)__popcll(todo_mask) >= PT_REGEN_MIN || __ballot(alive) == 0ull;
+        if (regen) {
         // ---- (1) finished pixels are flushed: one 16-B store (the 16-B load was issued when the
         //          pixel was taken, so its latency is long gone)
         if (!alive && my >= 0 && sample_i == a.count) {
@@ -320,6 +360,7 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
             if (NEE) { shadow = false; prev_pdf_b = -1.0f; }
             if (COUNT) c_samples++;
         }
+        }  // regen
         if (__ballot(alive) == 0ull) {
             // nothing in flight: done when no lane holds a pixel and the frame is exhausted;
             // otherwise some lane flushes / pulls on the next trip
