@@ -215,6 +215,22 @@ int pt_reset(PtContext* ctx);
  * Asynchronous on the context's stream. */
 int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
               const PtRenderParams* params);
+/* Frames in flight (1..4, default 1).  With n > 1, consecutive PT_ACC_SUM path
+ * launches go round-robin to n internal streams, each with an accumulator of
+ * its own, so launch k+1 fills the compute units that launch k leaves idle
+ * while its last long paths finish (the reference's frame loop,
+ * main.cu:284-303, serialises launch and display; there is no counterpart).
+ * The sums are folded into the context's accumulation buffer, in a fixed order,
+ * by pt_flush() and by every call that reads or replaces that buffer
+ * (pt_resolve, pt_readback*, pt_upload_accum, pt_reset, pt_sync, pt_counters,
+ * pt_bind_accum, pt_set_stream, pt_upload_scene, pt_resize); a caller that
+ * reads pt_accum_device_ptr() or a bound buffer itself calls pt_flush() first,
+ * which is asynchronous on the context's stream.  The image is reproducible
+ * run to run; it differs from the n = 1 image only by float summation order.
+ * A fused display (fused_rgba8) written while other launches are in flight
+ * shows, per pixel, a mean that may or may not include their newest sample. */
+int pt_set_frames_in_flight(PtContext* ctx, uint32_t n);
+int pt_flush(PtContext* ctx);
 /* Resolve the accumulation buffer into the context's display buffer
  * (convertToRGBAKernel / the CPU accumulate+gamma loop).  Asynchronous. */
 int pt_resolve(PtContext* ctx, uint32_t mode);

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <cstdlib>
 #include <string>
 #include <utility>
 #include <vector>
@@ -68,8 +69,19 @@ struct PtContext {
     uint64_t* counters = nullptr;  // 12 x u64
     uint32_t* ids = nullptr;       // 2 * npix, allocated on demand
     float* sink = nullptr;
-    uint32_t* work_counter = nullptr;  // tile tickets of the path kernel; never reset, see work_base
-    uint32_t work_parity = 0;          // which of the two counter sets the next launch uses
+    uint32_t* work_counter = nullptr;  // ticket counters of the path kernel: 4 chains x 2 alternating sets x 8 shards x 128 B
+    uint32_t work_parity[4] = {0, 0, 0, 0};  // per chain: which of its two sets the next launch uses
+    // frames in flight (pt_set_frames_in_flight): launch k of a burst goes to chain k % flight, which
+    // has its own stream and its own accumulator; chain 0's accumulator is the context's (or the bound one)
+    uint32_t flight = 1;
+    hipStream_t chain_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t chain_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_event = nullptr;
+    float4* chain_acc[4] = {nullptr, nullptr, nullptr, nullptr};  // [0] unused (= accum)
+    size_t chain_acc_pixels = 0;
+    uint32_t burst = 0;                // launches since the chains were last joined
+    uint64_t* trace = nullptr;         // PT_AMD_TRACE=<file>: per-wave timeline of the last launch (PT_TRACE kernel builds)
+    size_t trace_waves = 0;
     uint32_t resident_blocks[4] = {0, 0, 0, 0};  // per kernel variant (nee, count)
 };
 
@@ -81,9 +93,12 @@ int use(PtContext* ctx) {
     return PT_OK;
 }
 
+int join_chains(PtContext* ctx);
+
 int alloc_frame(PtContext* ctx, uint32_t w, uint32_t h) {
     if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) return fail(PT_ERR_INVALID, "bad frame size %ux%u", w, h);
     if (w == ctx->width && h == ctx->height && ctx->display) return PT_OK;
+    if (int rc = join_chains(ctx)) return rc;
     const size_t npix = (size_t)w * h;
     if (ctx->accum_own) { HIP_TRY(hipFree(ctx->accum_own)); ctx->accum_own = nullptr; }
     if (ctx->display) { HIP_TRY(hipFree(ctx->display)); ctx->display = nullptr; }
@@ -99,6 +114,45 @@ int alloc_frame(PtContext* ctx, uint32_t w, uint32_t h) {
         ctx->accum_bound = false;
     }
     ctx->accum = ctx->accum_own;
+    return PT_OK;
+}
+
+constexpr size_t WORK_SET_WORDS = 256;  // 8 shards x 32 words (128 B apart)
+
+// Frames in flight: makes the context's stream wait for every chain and folds the chains'
+// accumulators into the context's.  A no-op when no burst is open.
+int join_chains(PtContext* ctx) {
+    if (ctx->burst == 0) return PT_OK;
+    const uint32_t used = ctx->burst < ctx->flight ? ctx->burst : ctx->flight;
+    for (uint32_t c = 0; c < used; ++c) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->chain_done[c], 0));
+    if (used > 1) {
+        float4* c1 = ctx->chain_acc[1];
+        float4* c2 = used > 2 ? ctx->chain_acc[2] : nullptr;
+        float4* c3 = used > 3 ? ctx->chain_acc[3] : nullptr;
+        HIP_TRY(pt_launch_merge(ctx->accum, c1, c2, c3, ctx->width * ctx->height, ctx->stream));
+    }
+    ctx->burst = 0;
+    return PT_OK;
+}
+
+// Streams, events and accumulators of chains 1..flight-1 for the current frame size (zeroed).
+int prepare_chains(PtContext* ctx) {
+    const size_t npix = (size_t)ctx->width * ctx->height;
+    if (!ctx->fork_event) HIP_TRY(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+    for (uint32_t c = 0; c < ctx->flight; ++c) {
+        if (!ctx->chain_stream[c]) HIP_TRY(hipStreamCreateWithFlags(&ctx->chain_stream[c], hipStreamNonBlocking));
+        if (!ctx->chain_done[c]) HIP_TRY(hipEventCreateWithFlags(&ctx->chain_done[c], hipEventDisableTiming));
+    }
+    if (ctx->chain_acc_pixels != npix) {
+        for (uint32_t c = 1; c < 4; ++c)
+            if (ctx->chain_acc[c]) { HIP_TRY(hipFree(ctx->chain_acc[c])); ctx->chain_acc[c] = nullptr; }
+        ctx->chain_acc_pixels = npix;
+    }
+    for (uint32_t c = 1; c < ctx->flight; ++c)
+        if (!ctx->chain_acc[c]) {
+            HIP_TRY(hipMalloc((void**)&ctx->chain_acc[c], npix * sizeof(float4)));
+            HIP_TRY(hipMemsetAsync(ctx->chain_acc[c], 0, npix * sizeof(float4), ctx->stream));  // ordered before the fork event
+        }
     return PT_OK;
 }
 
@@ -135,7 +189,7 @@ inline uint32_t hash32(uint32_t x) {  // counter-RNG finaliser, DESIGN.md §RNG
 extern "C" {
 
 const char* pt_last_error(void) { return g_err.c_str(); }
-uint32_t pt_abi_version(void) { return 1u; }
+uint32_t pt_abi_version(void) { return 2u; }
 
 int pt_create(int device_id, PtContext** out) {
     if (!out) return fail(PT_ERR_INVALID, "out_ctx is null");
@@ -153,8 +207,8 @@ int pt_create(int device_id, PtContext** out) {
     e = hipMalloc((void**)&ctx->counters, 12 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMemset(ctx->counters, 0, 12 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->sink, 256);
-    if (e == hipSuccess) e = hipMalloc((void**)&ctx->work_counter, 2048);
-    if (e == hipSuccess) e = hipMemset(ctx->work_counter, 0, 2048);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->work_counter, 8 * WORK_SET_WORDS * 4);
+    if (e == hipSuccess) e = hipMemset(ctx->work_counter, 0, 8 * WORK_SET_WORDS * 4);
     if (e != hipSuccess) { pt_destroy(ctx); return fail(PT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e)); }
     *out = ctx;
     return PT_OK;
@@ -163,6 +217,13 @@ int pt_create(int device_id, PtContext** out) {
 int pt_destroy(PtContext* ctx) {
     if (!ctx) return PT_OK;
     (void)hipSetDevice(ctx->device);
+    for (int c = 0; c < 4; ++c) {
+        if (ctx->chain_stream[c]) { (void)hipStreamSynchronize(ctx->chain_stream[c]); (void)hipStreamDestroy(ctx->chain_stream[c]); }
+        if (ctx->chain_done[c]) (void)hipEventDestroy(ctx->chain_done[c]);
+        if (ctx->chain_acc[c]) (void)hipFree(ctx->chain_acc[c]);
+    }
+    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+    if (ctx->trace) (void)hipFree(ctx->trace);
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); }
     if (ctx->scene_arena) (void)hipFree(ctx->scene_arena);
     if (ctx->accum_own) (void)hipFree(ctx->accum_own);
@@ -179,18 +240,21 @@ int pt_destroy(PtContext* ctx) {
 
 int pt_set_stream(PtContext* ctx, void* hip_stream) {
     if (int rc = use(ctx)) return rc;
+    if (int rc = join_chains(ctx)) return rc;
     ctx->stream = (hipStream_t)hip_stream;
     return PT_OK;
 }
 
 int pt_use_own_stream(PtContext* ctx) {
     if (int rc = use(ctx)) return rc;
+    if (int rc = join_chains(ctx)) return rc;
     ctx->stream = ctx->own_stream;
     return PT_OK;
 }
 
 int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
     if (int rc = use(ctx)) return rc;
+    if (int rc = join_chains(ctx)) return rc;  // the stream is synchronised below, before the old scene is freed
     if (!s) return fail(PT_ERR_INVALID, "scene is null");
     const uint32_t ns = s->num_spheres, np = s->num_planes, nt = s->num_triangles, nm = s->num_materials;
     if (ns > PT_MAX_SPHERES || np > PT_MAX_PLANES || nt > PT_MAX_TRIANGLES || nm > PT_MAX_MATERIALS)
@@ -263,6 +327,14 @@ int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
             push4(a ? L[i].first : NAN, u2f(a ? L[i].second : 0u), b ? L[i + 1].first : NAN, u2f(b ? L[i + 1].second : 0u));
         }
     }
+    const size_t o_pla = f4.size();
+    for (uint32_t i = 0; i < np; ++i) {
+        const F3 n = pl_normal[i];
+        const float px = (float)s->pl_px[i], py = (float)s->pl_py[i], pz = (float)s->pl_pz[i];
+        const bool degenerate = n.x == 0.0f && n.y == 0.0f && n.z == 0.0f;
+        if (degenerate) push4(NAN, NAN, NAN, 0); else push4(n.x, n.y, n.z, -(px * n.x + py * n.y + pz * n.z));
+    }
+    if (np == 0) push4(NAN, NAN, NAN, 0);
     const size_t o_tri = f4.size();
     std::vector<F3> tri_normal(nt);
     for (uint32_t i = 0; i < nt; ++i) {
@@ -352,7 +424,7 @@ int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
     const uint32_t* U = (const uint32_t*)((const unsigned char*)ctx->scene_arena + b_f4);
     const double* D = (const double*)((const unsigned char*)ctx->scene_arena + b_f4 + b_u32);
     DevSceneF& sf = ctx->sf;
-    sf.sph = F + o_sph; sf.pl = F + o_pl; sf.axp = F + o_axp; sf.tri = F + o_tri; sf.rec = F + o_rec; sf.lights = F + o_lt;
+    sf.sph = F + o_sph; sf.pl = F + o_pl; sf.axp = F + o_axp; sf.pla = F + o_pla; sf.tri = F + o_tri; sf.rec = F + o_rec; sf.lights = F + o_lt;
     sf.ns = (int)ns; sf.np = (int)np; sf.nt = (int)nt; sf.nl = (int)nl;
     sf.npg = (int)general.size();
     sf.nax = (int)axis_list[0].size(); sf.nay = (int)axis_list[1].size(); sf.naz = (int)axis_list[2].size();
@@ -438,6 +510,7 @@ int pt_set_camera(PtContext* ctx, const PtCamera* c) {
 int pt_bind_accum(PtContext* ctx, void* dev_float4) {
     if (int rc = use(ctx)) return rc;
     if (ctx->width == 0) return fail(PT_ERR_STATE, "set the frame size (pt_set_camera / pt_resize) before binding a buffer");
+    if (int rc = join_chains(ctx)) return rc;  // samples in flight belong to the buffer bound so far
     if (dev_float4) {
         if (((uintptr_t)dev_float4 & 15u) != 0) return fail(PT_ERR_INVALID, "accumulation buffer must be 16-byte aligned");
         ctx->accum = (float4*)dev_float4; ctx->accum_bound = true;
@@ -450,6 +523,7 @@ int pt_bind_accum(PtContext* ctx, void* dev_float4) {
 int pt_reset(PtContext* ctx) {
     if (int rc = use(ctx)) return rc;
     if (!ctx->accum) return fail(PT_ERR_STATE, "no frame allocated");
+    if (int rc = join_chains(ctx)) return rc;  // leaves the other chains' accumulators zero
     HIP_TRY(hipMemsetAsync(ctx->accum, 0, (size_t)ctx->width * ctx->height * sizeof(float4), ctx->stream));
     return PT_OK;
 }
@@ -466,6 +540,7 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     if (prm->acc_mode > PT_ACC_RUNNING_MEAN) return fail(PT_ERR_INVALID, "unknown acc_mode %u", prm->acc_mode);
     if (prm->integrator == PT_INTEGRATOR_DIRECT) {
         if (prm->acc_mode != PT_ACC_SUM) return fail(PT_ERR_INVALID, "the direct integrator accumulates sums only");
+        if (int rc = join_chains(ctx)) return rc;
         HIP_TRY(pt_launch_direct(ctx->sd, ctx->cd, ctx->accum, sample_begin, sample_count, prm->seed, ctx->stream));
         ctx->last_acc_mode = PT_ACC_SUM;
         return PT_OK;
@@ -475,8 +550,29 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     if (prm->max_depth == 0) return fail(PT_ERR_INVALID, "max_depth must be at least 1");
     if (prm->acc_mode == PT_ACC_RUNNING_MEAN && sample_count != 1)
         return fail(PT_ERR_INVALID, "the running-mean mode adds one sample per launch, like renderKernel");
+    // frames in flight: sums only (a running mean is a recurrence on one buffer), and not while
+    // a per-launch trace is being written
+    const bool pipelined = ctx->flight > 1 && prm->acc_mode == PT_ACC_SUM && !getenv("PT_AMD_TRACE");
+    uint32_t chain = 0;
+    hipStream_t stream = ctx->stream;
+    if (pipelined) {
+        if (ctx->burst == 0) {
+            if (int rc = prepare_chains(ctx)) return rc;
+            HIP_TRY(hipEventRecord(ctx->fork_event, ctx->stream));
+        }
+        chain = ctx->burst % ctx->flight;
+        stream = ctx->chain_stream[chain];
+        if (ctx->burst < ctx->flight) HIP_TRY(hipStreamWaitEvent(stream, ctx->fork_event, 0));  // first launch of this chain in the burst
+    } else {
+        if (int rc = join_chains(ctx)) return rc;
+    }
     PathArgs a{};
-    a.accum = ctx->accum;
+    a.accum = chain == 0 ? ctx->accum : ctx->chain_acc[chain];
+    if (pipelined && prm->fused_rgba8) {
+        uint32_t k = 0;
+        for (uint32_t c = 0; c < ctx->flight; ++c)
+            if (c != chain) a.other[k++] = c == 0 ? ctx->accum : ctx->chain_acc[c];
+    }
     a.rgba = prm->fused_rgba8 ? (uint32_t*)ctx->display : nullptr;
     a.counters = (prm->flags & PT_FLAG_COUNTERS) ? ctx->counters : nullptr;
     a.s0 = sample_begin; a.count = sample_count;
@@ -500,11 +596,43 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     a.units_per_grab = upg < 1u ? 1u : (upg > 65536u ? 65536u : upg);
     uint32_t blocks = (units / a.units_per_grab + 3u) / 4u;  // no more waves than tickets ...
     if (blocks > resident) blocks = resident;                // ... and no more than are resident at once
+    {   // lane-parallel intersection pays while (rays in flight) x (per-ray cost) < cost of one 64-ray pass
+        const DevSceneF& f = ctx->sf;
+        const uint32_t serial = 25u * (uint32_t)f.ns + 7u * (uint32_t)(f.nax + f.nay + f.naz) + 13u * (uint32_t)f.npg + 35u * (uint32_t)f.nt;
+        const uint32_t per_ray = 40u + 27u * (((uint32_t)f.ns + 63u) / 64u) + 15u * (((uint32_t)f.np + 63u) / 64u) + 37u * (((uint32_t)f.nt + 63u) / 64u);
+        uint32_t few = serial / per_ray;
+        a.few_max = few > 48u ? 48u : few;
+        if (const char* e = getenv("PT_AMD_FEW_MAX")) a.few_max = (uint32_t)atoi(e);  // tuning experiments
+    }
+    if (const char* e = getenv("PT_AMD_MAX_BLOCKS")) { const uint32_t m = (uint32_t)atoi(e); if (m && blocks > m) blocks = m; }  // tuning experiments
     if (blocks < 8u) blocks = 8u;                            // every shard needs a block to serve its tiles
-    a.work_counter = ctx->work_counter + 256u * ctx->work_parity;
-    a.next_counter = ctx->work_counter + 256u * (ctx->work_parity ^ 1u);
-    HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, blocks, ctx->stream));
-    ctx->work_parity ^= 1u;
+    // launches of one chain are ordered on its stream (chain 0 also serves unpipelined launches, which
+    // join_chains() orders after it): each zeroes the set its successor on the same chain will use
+    a.work_counter = ctx->work_counter + WORK_SET_WORDS * (2u * chain + ctx->work_parity[chain]);
+    a.next_counter = ctx->work_counter + WORK_SET_WORDS * (2u * chain + (ctx->work_parity[chain] ^ 1u));
+    const char* trace_file = getenv("PT_AMD_TRACE");  // kernel-timeline experiments (tools/gpu_trace.py)
+    if (trace_file) {
+        const size_t waves = (size_t)blocks * 4u;
+        if (ctx->trace_waves < waves) {
+            if (ctx->trace) HIP_TRY(hipFree(ctx->trace));
+            HIP_TRY(hipMalloc((void**)&ctx->trace, waves * 64));
+            ctx->trace_waves = waves;
+        }
+        HIP_TRY(hipMemsetAsync(ctx->trace, 0, waves * 64, stream));
+        a.trace = ctx->trace;
+    } else a.trace = nullptr;
+    HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, blocks, stream));
+    if (pipelined) {
+        HIP_TRY(hipEventRecord(ctx->chain_done[chain], stream));
+        ctx->burst++;
+    }
+    if (trace_file) {
+        std::vector<uint64_t> host((size_t)blocks * 4u * 8u);
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(host.data(), ctx->trace, host.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(trace_file, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+    }
+    ctx->work_parity[chain] ^= 1u;
     ctx->last_acc_mode = prm->acc_mode;
     if (prm->fused_rgba8) ctx->display_bytes = (size_t)ctx->width * ctx->height * 4;
     return PT_OK;
@@ -514,6 +642,7 @@ int pt_resolve(PtContext* ctx, uint32_t mode) {
     if (int rc = use(ctx)) return rc;
     if (!ctx->accum) return fail(PT_ERR_STATE, "no frame allocated");
     if (mode > PT_RESOLVE_RGB8_PPM) return fail(PT_ERR_INVALID, "unknown resolve mode %u", mode);
+    if (int rc = join_chains(ctx)) return rc;
     const uint32_t npix = ctx->width * ctx->height;
     HIP_TRY(pt_launch_resolve(ctx->accum, ctx->display, npix, ctx->last_acc_mode, mode, ctx->stream));
     ctx->display_bytes = (size_t)npix * (mode == PT_RESOLVE_FLOAT_MEAN ? 16 : mode == PT_RESOLVE_RGB8_PPM ? 3 : 4);
@@ -525,6 +654,7 @@ int pt_readback(PtContext* ctx, void* host_dst, size_t bytes) {
     if (!host_dst) return fail(PT_ERR_INVALID, "host_dst is null");
     if (ctx->display_bytes == 0) return fail(PT_ERR_STATE, "nothing resolved yet");
     if (bytes > ctx->display_bytes) return fail(PT_ERR_INVALID, "asked for %zu bytes, display buffer holds %zu", bytes, ctx->display_bytes);
+    if (int rc = join_chains(ctx)) return rc;
     HIP_TRY(hipMemcpyAsync(host_dst, ctx->display, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PT_OK;
@@ -536,6 +666,7 @@ int pt_readback_accum(PtContext* ctx, float* host_dst, size_t bytes) {
     if (!ctx->accum) return fail(PT_ERR_STATE, "no frame allocated");
     const size_t have = (size_t)ctx->width * ctx->height * sizeof(float4);
     if (bytes > have) return fail(PT_ERR_INVALID, "asked for %zu bytes, accumulation buffer holds %zu", bytes, have);
+    if (int rc = join_chains(ctx)) return rc;
     HIP_TRY(hipMemcpyAsync(host_dst, ctx->accum, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PT_OK;
@@ -547,13 +678,28 @@ int pt_upload_accum(PtContext* ctx, const float* host_src, size_t bytes) {
     if (!ctx->accum) return fail(PT_ERR_STATE, "no frame allocated");
     const size_t have = (size_t)ctx->width * ctx->height * sizeof(float4);
     if (bytes != have) return fail(PT_ERR_INVALID, "checkpoint is %zu bytes, accumulation buffer is %zu", bytes, have);
+    if (int rc = join_chains(ctx)) return rc;
     HIP_TRY(hipMemcpyAsync(ctx->accum, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
 
+int pt_flush(PtContext* ctx) {
+    if (int rc = use(ctx)) return rc;
+    return join_chains(ctx);
+}
+
+int pt_set_frames_in_flight(PtContext* ctx, uint32_t n) {
+    if (int rc = use(ctx)) return rc;
+    if (n < 1 || n > 4) return fail(PT_ERR_INVALID, "frames in flight must be 1..4, got %u", n);
+    if (int rc = join_chains(ctx)) return rc;
+    ctx->flight = n;
+    return PT_OK;
+}
+
 int pt_sync(PtContext* ctx) {
     if (int rc = use(ctx)) return rc;
+    if (int rc = join_chains(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
@@ -578,6 +724,7 @@ int pt_counters(PtContext* ctx, PtCounters* out) {
     if (int rc = use(ctx)) return rc;
     if (!out) return fail(PT_ERR_INVALID, "out is null");
     static_assert(sizeof(PtCounters) == 12 * sizeof(uint64_t), "PtCounters is 12 u64 in kernel order");
+    if (int rc = join_chains(ctx)) return rc;
     HIP_TRY(hipMemcpyAsync(out, ctx->counters, sizeof(PtCounters), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PT_OK;
@@ -585,6 +732,7 @@ int pt_counters(PtContext* ctx, PtCounters* out) {
 
 int pt_reset_counters(PtContext* ctx) {
     if (int rc = use(ctx)) return rc;
+    if (int rc = join_chains(ctx)) return rc;
     HIP_TRY(hipMemsetAsync(ctx->counters, 0, 12 * sizeof(uint64_t), ctx->stream));
     return PT_OK;
 }

@@ -17,6 +17,7 @@ struct DevSceneF {
     const float4* pl;      // [2*npg4] general planes: (unit normal, -(point . normal)) | (bits(primitive id), 0, 0, 0)
     const float4* axp;     // axis-aligned planes, one list per axis (x | y | z), two planes per float4:
                            //          p_k, bits(primitive id), p_k, bits(primitive id); NaN-padded
+    const float4* pla;     // [np]     every plane in insertion order, general form (lane-parallel test)
     const float4* tri;     // [3*nt2]  rows of the world -> (u, v, height) affine map of the triangle
     const float4* rec;     // [4*(ns+np+nt)] winner record, one 64-B line per primitive:
                            //   0: sphere (cx,cy,cz,1/r) | plane, triangle (unit normal, 0)
@@ -44,9 +45,10 @@ struct DevCamF {
 struct PathArgs {
     float4* accum;
     uint32_t* rgba;          // display buffer (fused resolve) or nullptr
+    const float4* other[3];  // frames in flight: the other chains' accumulators (display only), nullptr-terminated
     uint64_t* counters;      // 12 x u64 (PtCounters order) or nullptr
     uint32_t* work_counter;  // this launch's 8 ticket counters on separate 128-B lines (word 32*s), zero at start
-    uint32_t* next_counter;  // the other set: zeroed by this launch for the next one
+    uint32_t* next_counter;  // the chain's other set: zeroed by this launch for the chain's next one
     float total_w, inv_total_w;  // (float)(s0 + count) and its reciprocal, for the fused display pack
     uint32_t s0, count;      // sample range of this launch
     uint32_t max_depth, rr_depth, seed_hash;
@@ -57,6 +59,8 @@ struct PathArgs {
     float inv_tiles_x;
     uint32_t units_per_grab;    // minimum 4x4-pixel units per ticket
     uint32_t num_tiles;
+    uint32_t few_max;           // lane-parallel intersection when at most this many lanes of a wave trace
+    uint64_t* trace;            // per-wave timeline, 8 x u64 per wave (PT_TRACE kernel builds only; else nullptr)
 };
 
 // ---- FP64 scene for the id pass and the `direct` integrator ---------------------------
@@ -89,6 +93,7 @@ hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArg
 hipError_t pt_path_resident_blocks(bool nee, bool count, int device, uint32_t* blocks);
 hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint32_t acc_mode, uint32_t mode,
                              hipStream_t stream);
+hipError_t pt_launch_merge(float4* acc0, float4* c1, float4* c2, float4* c3, uint32_t npix, hipStream_t stream);
 hipError_t pt_launch_valu_peak(float* sink, uint32_t packed, uint32_t iters, uint32_t blocks, hipStream_t stream);
 hipError_t pt_launch_primary_ids(const DevSceneD& sc, const DevCamD& cam, uint32_t* obj, uint32_t* mat,
                                  hipStream_t stream);

@@ -202,6 +202,72 @@ __device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, flo
     }
 }
 
+// ---- lane-parallel closest hit --------------------------------------------------------------
+// closest_hit() spends one instruction stream on 64 rays x all primitives; when only a few lanes
+// of the wave still trace (the end of a launch: paths of up to max_depth bounces, one or two per
+// wave) it costs the same ~25 instructions per primitive for those few rays, and the launch ends
+// when the slowest such wave does.  Here the roles are swapped: each ray in turn is broadcast to
+// the whole wave (v_readlane), lane i tests primitives i, i+64, ..., and a DPP min-reduction plus
+// one ballot find the winner.  Per ray that is ~120 instructions for a Cornell box instead of
+// ~460, and N/64 tests instead of N for large scenes.  Ties between primitives at exactly equal
+// t go to the lowest id here and to the first in list order (spheres, axis planes, general
+// planes, triangles) in closest_hit(); both are measure-zero events.
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_min(float v) {
+    v = fminf(v, dpp_f<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = fminf(v, dpp_f<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = fminf(v, dpp_f<0x141>(v));  // row_half_mirror
+    v = fminf(v, dpp_f<0x140>(v));  // row_mirror: every lane now holds the minimum of its row of 16
+    return fminf(fminf(readlane_f(v, 0), readlane_f(v, 16)), fminf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+
+// The first 64 primitives of each kind are staged in LDS by the block (5 KB) at kernel start:
+// a ds_read costs ~100 cycles where a global load that hits L2 costs ~1000, and in this mode the
+// wave has no other work to hide it behind.  Primitives beyond 64 of a kind come from global memory.
+struct FewLds {
+    float4 sph[64];
+    float4 pla[64];
+    float4 tri[3 * 64];
+};
+
+__device__ __forceinline__ f4v to_f4v(float4 a) { f4v r; r.x = a.x; r.y = a.y; r.z = a.z; r.w = a.w; return r; }
+
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit_few(const DevSceneF& sc, const FewLds& lds, uint64_t rays, int lane, V3 o, V3 d,
+                                                float& t_out, int& id_out, uint32_t& n_roots) {
+    while (rays != 0ull) {
+        const int L = __builtin_ctzll(rays);
+        rays &= rays - 1ull;
+        const V3 O = v3(readlane_f(o.x, L), readlane_f(o.y, L), readlane_f(o.z, L));
+        const V3 D = v3(readlane_f(d.x, L), readlane_f(d.y, L), readlane_f(d.z, L));
+        float tb = T_BEST_INIT;
+        int ib = -1;
+        // the first 64 of each kind from LDS (re-read per ray: keeping them in registers across the
+        // main loop costs a wave of occupancy), the rest from global memory
+        if (lane < sc.ns) sphere_test<COUNT>(to_f4v(lds.sph[lane]), lane, O, D, tb, ib, n_roots);
+        for (int i = 64 + lane; i - lane < sc.ns; i += 64)
+            if (i < sc.ns) sphere_test<COUNT>(to_f4v(sc.sph[i]), i, O, D, tb, ib, n_roots);
+        if (lane < sc.np) plane_test(to_f4v(lds.pla[lane]), sc.ns + lane, O, D, tb, ib);
+        for (int i = 64 + lane; i - lane < sc.np; i += 64)
+            if (i < sc.np) plane_test(to_f4v(sc.pla[i]), sc.ns + i, O, D, tb, ib);
+        if (lane < sc.nt)
+            tri_test(to_f4v(lds.tri[3 * lane]), to_f4v(lds.tri[3 * lane + 1]), to_f4v(lds.tri[3 * lane + 2]), sc.ns + sc.np + lane, O, D, tb, ib);
+        for (int i = 64 + lane; i - lane < sc.nt; i += 64)
+            if (i < sc.nt)
+                tri_test(to_f4v(sc.tri[3 * i]), to_f4v(sc.tri[3 * i + 1]), to_f4v(sc.tri[3 * i + 2]), sc.ns + sc.np + i, O, D, tb, ib);
+        const float tmin = wave_min(tb);  // tb is never NaN: every test stores only values that passed `<`
+        const int winner = __builtin_ctzll(__ballot(tb == tmin));
+        const int idw = __builtin_amdgcn_readlane(ib, winner);
+        if (lane == L) { t_out = tmin; id_out = idw; }
+    }
+}
+
 // Solid-angle pdf of picking one of nl sphere lights uniformly and sampling its cone from P.
 // Returns 0 when P is inside the light.  cosmax / wc / dc2 are by-products for the sampler.
 __device__ __forceinline__ float light_pdf(float4 lt, int nl, V3 P, float& cosmax, V3& wc, float& dc2) {
@@ -248,6 +314,14 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
     uint32_t unit0 = 0, pool_size = 0, pool_next = 0;  // wave-uniform; unit0 counts within the shard
     bool exhausted = false;                             // wave-uniform
     if (blockIdx.x == 0 && threadIdx.x < 8u) a.next_counter[threadIdx.x * 32u] = 0u;
+    __shared__ FewLds few_lds;
+    if (threadIdx.x < 64u) {
+        const int i = (int)threadIdx.x;
+        if (i < sc.ns) few_lds.sph[i] = sc.sph[i];
+        if (i < sc.np) few_lds.pla[i] = sc.pla[i];
+        if (i < sc.nt) { few_lds.tri[3 * i] = sc.tri[3 * i]; few_lds.tri[3 * i + 1] = sc.tri[3 * i + 1]; few_lds.tri[3 * i + 2] = sc.tri[3 * i + 2]; }
+    }
+    __syncthreads();
 
     // lane state
     int my = -1;             // pool index of the pixel this lane owns, -1 = none
@@ -267,6 +341,11 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
     uint32_t c_samples = 0, c_rays = 0, c_hits = 0, c_roots = 0, c_b0 = 0, c_b1 = 0, c_b2 = 0, c_b3 = 0, c_b4 = 0,
              c_diff = 0, c_nee = 0, c_shadow = 0;
     const bool need_prev = a.acc_mode == 0u || a.s0 > 0u;
+#ifdef PT_TRACE
+    // timeline of this wave (100 MHz constant clock): start, frame exhausted, first lane-parallel trip, end
+    uint64_t tr_start = wall_clock64(), tr_exh = 0, tr_few = 0;
+    uint32_t tr_trips = 0, tr_few_trips = 0, tr_few_rays = 0, tr_lane_trips = 0;
+#endif
 
     for (;;) {
         // Steps (1)-(3) run at the few lanes whose path just ended; executed on every trip they
@@ -294,9 +373,24 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
             }
             a.accum[pixel] = acc;
             if (a.rgba) {  // fused convertToRGBAKernel
-                // every pixel normally holds the same count: its reciprocal comes from the host (same IEEE divide)
-                const float inv = (a.acc_mode != 0u) ? 1.0f : (acc.w == a.total_w ? a.inv_total_w : 1.0f / acc.w);
-                a.rgba[pixel] = pack_rgba8_cuda(acc.x * inv, acc.y * inv, acc.z * inv);
+                if (a.other[0]) {
+                    // frames in flight: the displayed mean also counts the samples the other chains hold
+                    // for this pixel.  Their launches may be running, so this reads each (sum, n) either
+                    // before or after their 16-B store: a consistent mean either way, display only.
+                    float4 tot = acc;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        if (!a.other[k]) break;
+                        const float4 q = a.other[k][pixel];
+                        tot.x += q.x; tot.y += q.y; tot.z += q.z; tot.w += q.w;
+                    }
+                    const float inv = rcp(tot.w);
+                    a.rgba[pixel] = pack_rgba8_cuda(tot.x * inv, tot.y * inv, tot.z * inv);
+                } else {
+                    // every pixel normally holds the same count: its reciprocal comes from the host (same IEEE divide)
+                    const float inv = (a.acc_mode != 0u) ? 1.0f : (acc.w == a.total_w ? a.inv_total_w : 1.0f / acc.w);
+                    a.rgba[pixel] = pack_rgba8_cuda(acc.x * inv, acc.y * inv, acc.z * inv);
+                }
             }
             my = -1;
         }
@@ -312,6 +406,9 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
                 ticket = __builtin_amdgcn_readfirstlane(ticket);
                 if (ticket >= shard_units) {
                     exhausted = true;
+#ifdef PT_TRACE
+                    tr_exh = wall_clock64();
+#endif
                 } else {
                     unit0 = ticket;
                     pool_size = min(need, shard_units - ticket) * 16u;
@@ -367,10 +464,20 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
             if (__ballot(my >= 0) == 0ull && exhausted) break;
             continue;
         }
+        // ---- (4) one ray: 64 rays per instruction stream, or lane-parallel when few lanes trace
+        float t_hit = T_BEST_INIT; int id_hit = -1;
+        const uint64_t alive_mask = __ballot(alive);
+#ifdef PT_TRACE
+        tr_trips++; tr_lane_trips += (uint32_t)__popcll(alive_mask);
+        if ((uint32_t)__popcll(alive_mask) <= a.few_max) { if (!tr_few) tr_few = wall_clock64(); tr_few_trips++; tr_few_rays += (uint32_t)__popcll(alive_mask); }
+#endif
+        if ((uint32_t)__popcll(alive_mask) <= a.few_max) {  // wave-uniform: all lanes take part
+            closest_hit_few<COUNT>(sc, few_lds, alive_mask, (int)lane, o, d, t_hit, id_hit, c_roots);
+        } else if (alive) {
+            closest_hit<COUNT>(sc, o, d, t_hit, id_hit, c_roots);
+        }
         if (alive) {
-            // ---- (4) one ray
-            float t; int id;
-            closest_hit<COUNT>(sc, o, d, t, id, c_roots);
+            const float t = t_hit; const int id = id_hit;
             if (COUNT) { c_rays++; if (id >= 0) c_hits++; }
             bool end_path = false;
             if (id < 0) {
@@ -537,6 +644,13 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
         }
     }
 
+#ifdef PT_TRACE
+    if (a.trace && lane == 0) {
+        uint64_t* tr = a.trace + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u;
+        tr[0] = tr_start; tr[1] = tr_exh; tr[2] = tr_few; tr[3] = wall_clock64();
+        tr[4] = tr_trips; tr[5] = tr_few_trips; tr[6] = tr_few_rays; tr[7] = tr_lane_trips;
+    }
+#endif
     if (COUNT && a.counters) {
         uint32_t c[12] = {c_samples, c_rays, c_hits, c_roots, c_b0, c_b1, c_b2, c_b3, c_b4, c_diff, c_nee, c_shadow};
 #pragma unroll
@@ -579,6 +693,21 @@ __global__ __launch_bounds__(256) void pt_resolve_kernel(const float4* __restric
             o[k] = (uint8_t)(fminf(fmaxf(gm, 0.0f), 1.0f) * 255.0f + 0.5f);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Frames in flight: folds the chains' accumulators into the first one in a fixed order
+// (acc0 + acc1 + acc2 + acc3, so the result is reproducible) and clears the others.
+__global__ __launch_bounds__(256) void pt_merge_kernel(float4* __restrict__ acc0, float4* __restrict__ c1,
+                                                       float4* __restrict__ c2, float4* __restrict__ c3, uint32_t npix) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= npix) return;
+    float4 a = acc0[p];
+    const float4 zero = make_float4(0, 0, 0, 0);
+    if (c1) { const float4 q = c1[p]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; c1[p] = zero; }
+    if (c2) { const float4 q = c2[p]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; c2[p] = zero; }
+    if (c3) { const float4 q = c3[p]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; c3[p] = zero; }
+    acc0[p] = a;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -652,6 +781,11 @@ hipError_t pt_path_resident_blocks(bool nee, bool count, int device, uint32_t* b
 hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint32_t acc_mode, uint32_t mode,
                              hipStream_t stream) {
     hipLaunchKernelGGL(pt_resolve_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, accum, out, npix, acc_mode, mode);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_merge(float4* acc0, float4* c1, float4* c2, float4* c3, uint32_t npix, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_merge_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, acc0, c1, c2, c3, npix);
     return hipGetLastError();
 }
 

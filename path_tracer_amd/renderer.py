@@ -60,6 +60,14 @@ class Renderer:
     def use_own_stream(self):
         check(self._L.pt_use_own_stream(self._ctx))
 
+    def set_frames_in_flight(self, n: int):
+        """1..4 consecutive sum-mode launches overlap on internal streams (include/pt.h)."""
+        check(self._L.pt_set_frames_in_flight(self._ctx, n))
+
+    def flush(self):
+        """Fold the in-flight chains into the accumulation buffer (asynchronous)."""
+        check(self._L.pt_flush(self._ctx))
+
     def unbind(self):
         check(self._L.pt_bind_accum(self._ctx, None))
         self._bound = None

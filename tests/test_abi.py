@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in _declared_symbols():
         assert getattr(L, name) is not None
-    assert L.pt_abi_version() == 1
+    assert L.pt_abi_version() == 2
 
 
 def test_struct_sizes_match_the_header(tmp_path):

@@ -33,6 +33,12 @@ def _setup(r, scene, cam):
     r.reset()
 
 
+def _rgb(packed):
+    """RGBA8 words (R << 16 | G << 8 | B) -> int array [..., 3]."""
+    p = packed.astype(np.int64)
+    return np.stack([(p >> 16) & 255, (p >> 8) & 255, p & 255], axis=-1)
+
+
 def _mean(acc):
     return acc[..., :3] / np.maximum(acc[..., 3:4], 1.0)
 
@@ -359,6 +365,97 @@ def test_bound_torch_tensor_is_the_accumulation_buffer(gpu):
     gpu.use_own_stream()
     gpu.render(3, 1, abi.render_params())
     assert np.all(gpu.accum()[..., 3] == 4)  # back on the context's own buffer
+
+
+# ------------------------------------------------------------------ frames in flight ---
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_frames_in_flight_match_serial(gpu, n):
+    """Launches overlapped on n chains hold the same samples as serial launches: every pixel's
+    count is exact, the sums differ only by float summation order, and the result does not
+    depend on how the launches happened to overlap (bit-identical run to run)."""
+    sc, cam = scenes.cuda_default(320, 180)
+    frames = 11  # not a multiple of n: the chains end a burst with unequal counts
+    _setup(gpu, sc, cam)
+    for s in range(frames):
+        gpu.render(s, 1, abi.render_params(fused_rgba8=1))
+    serial = gpu.accum()
+    serial_rgba = gpu.resolve_to_host(abi.RESOLVE_RGBA8_CUDA)
+    gpu.set_frames_in_flight(n)
+    try:
+        runs = []
+        for rep in range(2):
+            _setup(gpu, sc, cam)
+            for s in range(frames):
+                gpu.render(s, 1, abi.render_params(fused_rgba8=1))
+            runs.append(gpu.accum())     # reads join the chains
+        assert np.array_equal(runs[0], runs[1])
+        assert np.all(runs[0][..., 3] == frames)
+        np.testing.assert_allclose(runs[0][..., :3], serial[..., :3], rtol=2e-6, atol=1e-6)
+        d = np.abs(_rgb(gpu.resolve_to_host(abi.RESOLVE_RGBA8_CUDA)) - _rgb(serial_rgba))
+        assert d.max() <= 1
+        # a burst, a serial-only launch (running mean is never pipelined) and another burst
+        _setup(gpu, sc, cam)
+        for s in range(5):
+            gpu.render(s, 2, abi.render_params())        # 2 spp per launch
+        gpu.flush()
+        for s in range(5, 8):
+            gpu.render(s, 2, abi.render_params())
+        got = gpu.accum()
+        assert np.all(got[..., 3] == 16)
+        _setup(gpu, sc, cam)
+        gpu.set_frames_in_flight(1)
+        for s in range(8):
+            gpu.render(s, 2, abi.render_params())
+        np.testing.assert_allclose(got[..., :3], gpu.accum()[..., :3], rtol=2e-6, atol=1e-6)
+    finally:
+        gpu.set_frames_in_flight(1)
+
+
+def test_frames_in_flight_full_size_and_reset(gpu):
+    sc, cam = scenes.cuda_default(1280, 720)
+    _setup(gpu, sc, cam)
+    gpu.set_frames_in_flight(3)
+    try:
+        for s in range(32):
+            gpu.render(s, 1, abi.render_params(fused_rgba8=1))
+        acc = gpu.accum()
+        assert np.all(acc[..., 3] == 32) and np.isfinite(acc).all()
+        fused = gpu.readback(abi.RESOLVE_RGBA8_CUDA)      # written by the last launches while others ran
+        d = np.abs(_rgb(fused) - _rgb(gpu.resolve_to_host(abi.RESOLVE_RGBA8_CUDA)))
+        assert (d > 48).mean() < 0.01                     # a preview: it may lack the newest sample of other chains
+        gpu.render(32, 1, abi.render_params())
+        gpu.reset()                                       # discards the open burst too
+        assert not gpu.accum().any()
+        gpu.render(0, 1, abi.render_params())
+        gpu.render(1, 1, abi.render_params())
+        assert np.all(gpu.accum()[..., 3] == 2)
+    finally:
+        gpu.set_frames_in_flight(1)
+
+
+def test_frames_in_flight_with_bound_tensor(gpu):
+    import torch
+    sc, cam = scenes.cuda_default(160, 90)
+    _setup(gpu, sc, cam)
+    for s in range(6):
+        gpu.render(s, 1, abi.render_params())
+    want = gpu.accum()
+    t = torch.zeros((90, 160, 4), device="cuda", dtype=torch.float32)
+    gpu.use_torch_stream()
+    gpu.bind_tensor(t)
+    gpu.set_frames_in_flight(2)
+    try:
+        for s in range(6):
+            gpu.render(s, 1, abi.render_params())
+        gpu.flush()                                       # the tensor is read by torch, not by the library
+        torch.cuda.synchronize()
+        got = t.cpu().numpy()
+        assert np.all(got[..., 3] == 6)
+        np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=2e-6, atol=1e-6)
+    finally:
+        gpu.set_frames_in_flight(1)
+        gpu.unbind()
+        gpu.use_own_stream()
 
 
 # -------------------------------------------------------------------------- error paths ---

@@ -7,7 +7,9 @@ import sys, time, json
 sys.path.insert(0, %r)
 from path_tracer_amd import abi, scenes
 from path_tracer_amd.renderer import Renderer
+import os
 r = Renderer(0); out = {}
+if os.environ.get("PT_FLIGHT"): r.set_frames_in_flight(int(os.environ["PT_FLIGHT"]))
 def timeit(name, sc, cam, params, spl, launches, warm=2):
     r.set_scene(sc); r.set_camera(cam); r.reset()
     best = 0
@@ -34,7 +36,10 @@ print(json.dumps(out))
 res = {}
 for v in sys.argv[1:]:
     env = dict(os.environ)
-    if v != "main": env["PT_AMD_LIB"] = os.path.join(ROOT, "path_tracer_amd", "lib", f"libpt_amd_{v}.so")
+    if v.startswith("blocks="): env["PT_AMD_MAX_BLOCKS"] = v.split("=")[1]
+    elif v.startswith("flight="): env["PT_FLIGHT"] = v.split("=")[1]
+    elif v.startswith("few="): env["PT_AMD_FEW_MAX"] = v.split("=")[1]
+    elif v != "main": env["PT_AMD_LIB"] = os.path.join(ROOT, "path_tracer_amd", "lib", f"libpt_amd_{v}.so")
     p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=280)
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     res[v] = json.loads(line[-1]) if line else {"error": p.stderr[-400:]}

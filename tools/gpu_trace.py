@@ -1,0 +1,41 @@
+"""Per-wave timeline of one launch (needs a PT_TRACE kernel build: make variant NAME=trace KFLAGS="-fno-slp-vectorize -DPT_TRACE").
+python tools/gpu_trace.py [few_max]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+os.environ["PT_AMD_LIB"] = os.path.join(ROOT, "path_tracer_amd", "lib", "libpt_amd_trace.so")
+os.environ["PT_AMD_TRACE"] = "/tmp/pt_trace.bin"
+if len(sys.argv) > 1: os.environ["PT_AMD_FEW_MAX"] = sys.argv[1]
+import numpy as np
+from path_tracer_amd import abi, scenes
+from path_tracer_amd.renderer import Renderer
+r = Renderer(0)
+for name, (w, h), spp in (("cuda_default", (1280, 720), 1), ("cuda_default", (1280, 720), 16), ("cuda_default", (3840, 2160), 16)):
+    sc, cam = scenes.builtin(name, w, h)
+    r.set_scene(sc); r.set_camera(cam); r.reset()
+    for i in range(3): r.render(i * spp, spp, abi.render_params(fused_rgba8=1))
+    r.sync()
+    t = np.fromfile("/tmp/pt_trace.bin", dtype=np.uint64).reshape(-1, 8)
+    t = t[t[:, 0] > 0]
+    t0 = t[:, 0].min()
+    us = lambda x: (x.astype(np.float64) - float(t0)) / 100.0   # 100 MHz
+    start, exh, few, end = us(t[:, 0]), us(t[:, 1]), us(t[:, 2]), us(t[:, 3])
+    trips, ftrips, frays, ltrips = (t[:, k].astype(np.float64) for k in (4, 5, 6, 7))
+    q = lambda x: np.percentile(x, [0, 10, 50, 90, 99, 100]).round(1).tolist()
+    print(f"== {name} {w}x{h} {spp} spp: {len(t)} waves, launch span {end.max():.1f} us")
+    print("   start            pct[0,10,50,90,99,100]", q(start))
+    print("   frame exhausted  ", q(exh[t[:, 1] > 0]))
+    print("   first few-trip   ", q(few[t[:, 2] > 0]))
+    print("   end              ", q(end))
+    print("   end - exhausted  ", q((end - exh)[t[:, 1] > 0]))
+    print("   trips/wave       ", q(trips), " few-mode trips/wave", q(ftrips), " few rays/wave", q(frays))
+    print(f"   lane utilisation of trips: {ltrips.sum() / (64 * trips.sum()):.3f};  few-mode share of trips {ftrips.sum() / trips.sum():.3f}")
+    busy = end - start
+    print(f"   mean trip time normal {((busy.sum()) / trips.sum()):.3f} us")
+    late = np.argsort(end)[-5:]
+    for i in late:
+        fe = (end[i] - few[i]) if t[i, 2] > 0 else 0.0
+        print(f"     late wave: end {end[i]:.1f} exh {exh[i]:.1f} few-start {few[i]:.1f} trips {int(trips[i])} few-trips {int(ftrips[i])} -> {fe / max(ftrips[i], 1):.3f} us per few-trip")
+    # how much of the chip is busy over time
+    grid = np.linspace(0, end.max(), 21)
+    act = [(int(((start <= g) & (end > g)).sum())) for g in grid]
+    print("   active waves over time:", act)
