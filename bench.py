@@ -49,9 +49,15 @@ def main() -> int:
     ap.add_argument("--workload", default="cornell_720p_progressive_1spp", choices=sorted(WORKLOADS))
     ap.add_argument("--mis", action="store_true", help="next-event estimation + MIS (north_star variant)")
     ap.add_argument("--pixels-per-wave", type=int, default=0)
+    ap.add_argument("--frames-in-flight", type=int, default=3, choices=(1, 2, 3, 4),
+                    help="consecutive launches overlapped on internal streams (include/pt.h); 1 = strictly serial launches")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
     args = ap.parse_args()
 
+    # frames in flight need one hardware queue per chain plus the launch stream; HIP's default of 4
+    # per process makes two of them share a queue (and serialise) from 3 chains on
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
     import torch
     import torch.distributed as dist
 
@@ -82,6 +88,7 @@ def main() -> int:
     r.set_camera(cam)
     accum = torch.zeros((H, W, 4), device="cuda", dtype=torch.float32)
     r.bind_tensor(accum)
+    r.set_frames_in_flight(args.frames_in_flight)
 
     K, Wm = args.steps, args.warmup
     sched = progressive_schedule(0, Wm + K, world, rank, spp)
@@ -93,6 +100,7 @@ def main() -> int:
 
     for s0, n in sched[:Wm]:
         r.render(s0, n, params)
+    r.flush()
     if world > 1:  # warm the collective too
         reduce_accum(accum.clone())
     barrier()
@@ -101,6 +109,7 @@ def main() -> int:
     ev0.record()
     for s0, n in sched[Wm:]:
         r.render(s0, n, params)
+    r.flush()  # frames in flight: the launch stream waits for every chain and folds their sums (asynchronous)
     ev1.record()
     if world > 1:
         reduce_accum(accum, dst=0)
@@ -108,7 +117,22 @@ def main() -> int:
         r.resolve(abi.RESOLVE_RGBA8_CUDA)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / K  # average launch duration, back-to-back launches on the launch stream
+    # HIP events on the launch stream around the K launches (the chains fork from and join this stream):
+    # the time per launch the chip needed, with `frames_in_flight` launches overlapping
+    kernel_ms = ev0.elapsed_time(ev1) / K
+    # the same launches strictly one after another, for comparison with rocprofv3's per-dispatch durations
+    serial_ms = kernel_ms
+    if args.frames_in_flight > 1:
+        r.set_frames_in_flight(1)
+        n_serial = min(K, 128)
+        torch.cuda.synchronize()
+        ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev2.record()
+        for s0, n in sched[Wm:Wm + n_serial]:
+            r.render(s0, n, params)
+        ev3.record()
+        torch.cuda.synchronize()
+        serial_ms = ev2.elapsed_time(ev3) / n_serial
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -144,14 +168,16 @@ def main() -> int:
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "spp_per_step": spp,
                        "max_depth": max_depth, "integrator": "path+nee_mis" if args.mis else "path",
-                       "accumulate": "sum+fused_rgba8", "parallelism": f"sample_split{world}" if world > 1 else "single",
+                       "accumulate": "sum+fused_rgba8", "frames_in_flight": args.frames_in_flight, "parallelism": f"sample_split{world}" if world > 1 else "single",
                        "reduce": "rccl_reduce_sum_once" if world > 1 else None},
             "mrays_per_s": round(value * rays_per_sample, 1), "rays_per_sample": round(rays_per_sample, 4),
             "roofline": {"bound": "valu", "kernel": "pt_path_kernel", "achieved": round(achieved, 4),
                          "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5),
                          "traffic": traffic, "flops_per_launch": flops_per_launch,
                          "flops_per_sample": round(flops_per_launch / samples_per_step, 1),
-                         "kernel_ms": round(kernel_ms, 5)},
+                         "kernel_ms": round(kernel_ms, 5), "launch_overlap": args.frames_in_flight,
+                         "kernel_ms_serial": round(serial_ms, 5),
+                         "frac_serial": round(flops_per_launch / (serial_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 5)},
         }
         if world == 1 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(scene, cam, params, spp, args.cpu_seconds)

@@ -139,6 +139,9 @@ int join_chains(PtContext* ctx) {
 int prepare_chains(PtContext* ctx) {
     const size_t npix = (size_t)ctx->width * ctx->height;
     if (!ctx->fork_event) HIP_TRY(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+    // chain 0 runs on the context's own stream: one stream fewer to share the process's hardware
+    // queues (GPU_MAX_HW_QUEUES, 4 by default; two chains on one queue serialise)
+    ctx->chain_stream[0] = ctx->own_stream;
     for (uint32_t c = 0; c < ctx->flight; ++c) {
         if (!ctx->chain_stream[c]) HIP_TRY(hipStreamCreateWithFlags(&ctx->chain_stream[c], hipStreamNonBlocking));
         if (!ctx->chain_done[c]) HIP_TRY(hipEventCreateWithFlags(&ctx->chain_done[c], hipEventDisableTiming));
@@ -218,7 +221,7 @@ int pt_destroy(PtContext* ctx) {
     if (!ctx) return PT_OK;
     (void)hipSetDevice(ctx->device);
     for (int c = 0; c < 4; ++c) {
-        if (ctx->chain_stream[c]) { (void)hipStreamSynchronize(ctx->chain_stream[c]); (void)hipStreamDestroy(ctx->chain_stream[c]); }
+        if (c > 0 && ctx->chain_stream[c]) { (void)hipStreamSynchronize(ctx->chain_stream[c]); (void)hipStreamDestroy(ctx->chain_stream[c]); }
         if (ctx->chain_done[c]) (void)hipEventDestroy(ctx->chain_done[c]);
         if (ctx->chain_acc[c]) (void)hipFree(ctx->chain_acc[c]);
     }
