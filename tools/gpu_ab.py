@@ -36,10 +36,12 @@ print(json.dumps(out))
 res = {}
 for v in sys.argv[1:]:
     env = dict(os.environ)
-    if v.startswith("blocks="): env["PT_AMD_MAX_BLOCKS"] = v.split("=")[1]
-    elif v.startswith("flight="): env["PT_FLIGHT"] = v.split("=")[1]
-    elif v.startswith("few="): env["PT_AMD_FEW_MAX"] = v.split("=")[1]
-    elif v != "main": env["PT_AMD_LIB"] = os.path.join(ROOT, "path_tracer_amd", "lib", f"libpt_amd_{v}.so")
+    for kv in v.split(","):   # e.g. flight=3,blocks=768,few=2 or a variant library name
+        if kv.startswith("blocks="): env["PT_AMD_MAX_BLOCKS"] = kv.split("=")[1]
+        elif kv.startswith("flight="): env["PT_FLIGHT"] = kv.split("=")[1]
+        elif kv.startswith("few="): env["PT_AMD_FEW_MAX"] = kv.split("=")[1]
+        elif kv.startswith("queues="): env["GPU_MAX_HW_QUEUES"] = kv.split("=")[1]
+        elif kv != "main": env["PT_AMD_LIB"] = os.path.join(ROOT, "path_tracer_amd", "lib", f"libpt_amd_{kv}.so")
     p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=280)
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     res[v] = json.loads(line[-1]) if line else {"error": p.stderr[-400:]}
