@@ -517,123 +517,124 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
                         }
                         if (COUNT) c_b4++;
                         end_path = true;  // Emissive_t::scatter returns false
-                    } else if (mtype == MAT_LAMBERTIAN) {
-                        if (COUNT) c_b0++;
+                    } else {
+                        // ---- scatter.  The four BSDFs share what they have in common, so a wave that
+                        // holds all of them (every wave, after the first bounce) runs it once and not
+                        // four times: the two uniform draws, the mirror direction, the final
+                        // normalisation (Ray_t's constructor, Ray.cuh:43-53), the origin offset and the
+                        // throughput product.  Per lane the arithmetic is what the separate
+                        // Material.cuh scatter functions do, in the same order.
                         const uint32_t slot = depth + 1u;
+                        const float u0 = uni(pt_draw(key, slot, 0));
+                        const float u1 = uni(pt_draw(key, slot, 1));
+                        const V3 refl = d - n * (2.0f * dot(d, n));
+                        V3 dir = refl;                // un-normalised scattered direction
+                        V3 tint = albedo;             // throughput factor
+                        float eps = RAY_OFFSET;       // Material.cuh:64,115,173; Glossy_t uses none (:204)
                         bool do_shadow = false;
-                        if (NEE && sc.nl > 0) {
-                            // next-event estimation with balance-heuristic MIS (north_star addition)
-                            if (COUNT) c_nee++;
-                            const uint32_t j = __umulhi(pt_draw(key, slot, 4), (uint32_t)sc.nl);
-                            const float u1 = uni(pt_draw(key, slot, 5)), u2 = uni(pt_draw(key, slot, 6));
-                            float cosmax, dc2; V3 wc;
-                            const float pl = light_pdf(sc.lights[3 * j], sc.nl, p, cosmax, wc, dc2);
-                            if (pl > 0.0f) {
-                                const float cost = 1.0f - u1 * (1.0f - cosmax);
-                                const float sint = fsqrt(fmaxf(0.0f, 1.0f - cost * cost));
-                                const V3 w = wc * rsq(dc2);
-                                V3 uu, vv; onb(w, uu, vv);
-                                const V3 dir = normalized(uu * (cos2pi(u2) * sint) + vv * (sin2pi(u2) * sint) + w * cost);
-                                const float cosN = dot(n, dir);
-                                if (cosN > 0.0f) {
-                                    const float pb = cosN * INV_PI;
-                                    const float wgt = pb * rcp(pl + pb);
-                                    const float4 l1 = sc.lights[3 * j + 1];
-                                    const V3 Ls = a.light_colour ? xyz(sc.lights[3 * j + 2]) : xyz(l1);
-                                    contrib = beta * albedo * Ls * wgt;
-                                    expect = (int)__float_as_uint(l1.w);
-                                    do_shadow = true;
-                                    pend_o = p + dir * RAY_OFFSET;  // shadow ray, same offset rule as a scattered ray
-                                    pend_d = dir;
+                        if (mtype == MAT_LAMBERTIAN) {
+                            if (COUNT) c_b0++;
+                            if (NEE && sc.nl > 0) {
+                                // next-event estimation with balance-heuristic MIS (north_star addition)
+                                if (COUNT) c_nee++;
+                                const uint32_t j = __umulhi(pt_draw(key, slot, 4), (uint32_t)sc.nl);
+                                const float v1 = uni(pt_draw(key, slot, 5)), v2 = uni(pt_draw(key, slot, 6));
+                                float cosmax, dc2; V3 wc;
+                                const float pl = light_pdf(sc.lights[3 * j], sc.nl, p, cosmax, wc, dc2);
+                                if (pl > 0.0f) {
+                                    const float cost = 1.0f - v1 * (1.0f - cosmax);
+                                    const float sint = fsqrt(fmaxf(0.0f, 1.0f - cost * cost));
+                                    const V3 w = wc * rsq(dc2);
+                                    V3 uu, vv; onb(w, uu, vv);
+                                    const V3 ldir = normalized(uu * (cos2pi(v2) * sint) + vv * (sin2pi(v2) * sint) + w * cost);
+                                    const float cosN = dot(n, ldir);
+                                    if (cosN > 0.0f) {
+                                        const float pb = cosN * INV_PI;
+                                        const float wgt = pb * rcp(pl + pb);
+                                        const float4 l1 = sc.lights[3 * j + 1];
+                                        const V3 Ls = a.light_colour ? xyz(sc.lights[3 * j + 2]) : xyz(l1);
+                                        contrib = beta * albedo * Ls * wgt;
+                                        expect = (int)__float_as_uint(l1.w);
+                                        do_shadow = true;
+                                        pend_o = p + ldir * RAY_OFFSET;  // shadow ray, same offset rule as a scattered ray
+                                        pend_d = ldir;
+                                    }
                                 }
                             }
+                            // Lambertian_t::scatter, Material.cuh:43-70: cosine-weighted direction about n
+                            V3 uu, vv; onb(n, uu, vv);
+                            const float r2s = fsqrt(u1);
+                            dir = uu * (cos2pi(u0) * r2s) + vv * (sin2pi(u0) * r2s) + n * fsqrt(1.0f - u1);
+                        } else if (mtype == MAT_DIELECTRIC) {
+                            // Dielectric_t::scatter, Material.cuh:149-175
+                            if (COUNT) c_b2++;
+                            const float ior = g2.z;
+                            const float eta = front ? rcp(ior) : ior;
+                            const float cos_theta = fminf(-dot(d, n), 1.0f);
+                            const float sin_theta = fsqrt(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
+                            const bool cannot = eta * sin_theta > 1.0f;
+                            float r0 = (1.0f - eta) * rcp(1.0f + eta); r0 *= r0;
+                            const float m1 = 1.0f - cos_theta, m2 = m1 * m1;
+                            const float sch = r0 + (1.0f - r0) * (m2 * m2 * m1);  // powf(1-cos, 5), :143
+                            if (!(cannot || sch > u0)) {  // refract, :133-138 (else: the mirror direction)
+                                const V3 perp = (d + n * cos_theta) * eta;
+                                const V3 par = n * -fsqrt(fabsf(1.0f - dot(perp, perp)));
+                                dir = perp + par;
+                            }
+                            tint = v3(1, 1, 1);
+                        } else {
+                            const float rough = g2.x;  // clamped to <= 1 for Metal at upload (Material.cuh:94)
+                            V3 pv;
+                            if (mtype == MAT_METAL) {
+                                // Metal_t::scatter, Material.cuh:97-121 (roughness 0: refl + pv * 0 == refl)
+                                if (COUNT) c_b1++;
+                                pv = v3(u0 * 2.0f - 1.0f, u1 * 2.0f - 1.0f, uni(pt_draw(key, slot, 2)) * 2.0f - 1.0f);
+                            } else {
+                                // Glossy_t::scatter, Material.cuh:191-213; Random_t::randomUnitVector, Random.cuh:36-45
+                                if (COUNT) c_b3++;
+                                const float z = -1.0f + 2.0f * u0;
+                                const float r = fsqrt(fmaxf(0.0f, 1.0f - z * z));
+                                pv = normalized(v3(r * cos2pi(u1), r * sin2pi(u1), z));
+                                const float m = g2.y;
+                                const V3 spec = m > 0.5f ? albedo : v3(1, 1, 1);
+                                tint = v3(albedo.x * (1.0f - m) + spec.x * m, albedo.y * (1.0f - m) + spec.y * m,
+                                          albedo.z * (1.0f - m) + spec.z * m);
+                                eps = 0.0f;
+                            }
+                            dir = refl + pv * rough;
                         }
-                        // Lambertian_t::scatter, Material.cuh:43-70
-                        V3 uu, vv; onb(n, uu, vv);
-                        const float x1 = uni(pt_draw(key, slot, 0));
-                        const float r2 = uni(pt_draw(key, slot, 1));
-                        const float r2s = fsqrt(r2);
-                        const V3 dir = normalized(uu * (cos2pi(x1) * r2s) + vv * (sin2pi(x1) * r2s) + n * fsqrt(1.0f - r2));
-                        const float cosine = dot(n, dir);
-                        bool go = cosine > 0.0f;  // pdf > 0 (the reference's 0*inf NaN case ends the path)
-                        // throughput *= albedo * scatteringPdf / pdf  (:229-230; the ratio is 1)
-                        beta = beta * albedo;
-                        if (COUNT) { if (go) c_diff++; }
-                        if (go && depth > a.rr_depth) {  // :233-239
-                            const float pr = fmaxf(beta.x, fmaxf(beta.y, beta.z));
-                            if (uni(pt_draw(key, slot, 3)) > pr) go = false;
-                            else beta = beta * rcp(pr);
+                        dir = normalized(dir);
+                        float cosine = dot(n, dir);
+                        if (mtype > MAT_DIELECTRIC && cosine < 0.0f) { dir = normalized(refl); cosine = dot(n, dir); }  // Glossy, :199-201
+                        beta = beta * tint;  // throughput *= albedo * scatteringPdf / pdf (:229-230; the ratio is 1)
+                        bool go = true;
+                        if (mtype == MAT_LAMBERTIAN) {
+                            go = cosine > 0.0f;  // pdf > 0 (the reference's 0*inf NaN case ends the path)
+                            if (COUNT) { if (go) c_diff++; }
+                            if (go && depth > a.rr_depth) {  // :233-239
+                                const float pr = fmaxf(beta.x, fmaxf(beta.y, beta.z));
+                                if (uni(pt_draw(key, slot, 3)) > pr) go = false;
+                                else beta = beta * rcp(pr);
+                            }
+                        } else if (mtype == MAT_METAL) {
+                            go = cosine > 0.0f;  // Metal_t::scatter returns dot(scattered, normal) > 0
                         }
-                        const V3 no = p + dir * RAY_OFFSET;
+                        o = p + dir * eps;
+                        d = dir;
                         if (NEE) {
-                            prev_pdf_b = cosine * INV_PI;
+                            prev_pdf_b = mtype == MAT_LAMBERTIAN ? cosine * INV_PI : -1.0f;
                             if (do_shadow) {
+                                // the shadow ray goes first; the scattered ray waits in pend_*
                                 if (COUNT) c_shadow++;
                                 const V3 so = pend_o, sd = pend_d;
-                                pend_o = no; pend_d = dir;
+                                pend_o = o; pend_d = d;
                                 o = so; d = sd;
                                 shadow = true;
                                 cont = go && (depth + 1u < a.max_depth);
                                 go = true;  // the shadow ray is traced regardless
-                            } else { o = no; d = dir; }
-                        } else { o = no; d = dir; }
+                            }
+                        }
                         if (!go) end_path = true;
-                    } else if (mtype == MAT_METAL) {
-                        // Metal_t::scatter, Material.cuh:97-121
-                        if (COUNT) c_b1++;
-                        const float rough = g2.x;
-                        V3 refl = d - n * (2.0f * dot(d, n));
-                        if (rough > 0.0f) {
-                            const uint32_t slot = depth + 1u;
-                            const V3 rnd = v3(uni(pt_draw(key, slot, 0)) * 2.0f - 1.0f, uni(pt_draw(key, slot, 1)) * 2.0f - 1.0f,
-                                              uni(pt_draw(key, slot, 2)) * 2.0f - 1.0f);
-                            refl = refl + rnd * rough;
-                        }
-                        refl = normalized(refl);  // Ray_t's constructor, Ray.cuh:43-53
-                        o = p + refl * RAY_OFFSET; d = refl;
-                        beta = beta * albedo;
-                        if (NEE) prev_pdf_b = -1.0f;
-                        if (!(dot(refl, n) > 0.0f)) end_path = true;
-                    } else if (mtype == MAT_DIELECTRIC) {
-                        // Dielectric_t::scatter, Material.cuh:149-175
-                        if (COUNT) c_b2++;
-                        const float ior = g2.z;
-                        const float eta = front ? rcp(ior) : ior;
-                        const float cos_theta = fminf(-dot(d, n), 1.0f);
-                        const float sin_theta = fsqrt(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
-                        const bool cannot = eta * sin_theta > 1.0f;
-                        float r0 = (1.0f - eta) * rcp(1.0f + eta); r0 *= r0;
-                        const float m1 = 1.0f - cos_theta, m2 = m1 * m1;
-                        const float sch = r0 + (1.0f - r0) * (m2 * m2 * m1);  // powf(1-cos, 5), :143
-                        V3 dir;
-                        if (cannot || sch > uni(pt_draw(key, depth + 1u, 0))) {
-                            dir = d - n * (2.0f * dot(d, n));
-                        } else {  // refract, :133-138
-                            const V3 perp = (d + n * cos_theta) * eta;
-                            const V3 par = n * -fsqrt(fabsf(1.0f - dot(perp, perp)));
-                            dir = perp + par;
-                        }
-                        dir = normalized(dir);
-                        o = p + dir * RAY_OFFSET; d = dir;
-                        if (NEE) prev_pdf_b = -1.0f;
-                    } else {
-                        // Glossy_t::scatter, Material.cuh:191-213
-                        if (COUNT) c_b3++;
-                        const V3 refl = d - n * (2.0f * dot(d, n));
-                        const uint32_t slot = depth + 1u;
-                        // Random_t::randomUnitVector, Random.cuh:36-45
-                        const float z = -1.0f + 2.0f * uni(pt_draw(key, slot, 0));
-                        const float tt = uni(pt_draw(key, slot, 1));
-                        const float r = fsqrt(fmaxf(0.0f, 1.0f - z * z));
-                        const V3 rv = normalized(v3(r * cos2pi(tt), r * sin2pi(tt), z));
-                        V3 sd = normalized(refl + rv * g2.x);
-                        if (dot(sd, n) < 0.0f) sd = normalized(refl);
-                        o = p; d = sd;  // no origin offset, :204
-                        const float m = g2.y;
-                        const V3 spec = m > 0.5f ? albedo : v3(1, 1, 1);
-                        beta = beta * v3(albedo.x * (1.0f - m) + spec.x * m, albedo.y * (1.0f - m) + spec.y * m,
-                                         albedo.z * (1.0f - m) + spec.z * m);
-                        if (NEE) prev_pdf_b = -1.0f;
                     }
                     // for (depth = 0; depth < max_depth; depth++), :206
                     depth++;
