@@ -59,6 +59,7 @@ struct PathArgs {
     float inv_tiles_x;
     uint32_t units_per_grab;    // minimum 4x4-pixel units per ticket
     uint32_t num_tiles;
+    uint32_t width, height;     // frame size (filled by pt_launch_path from the camera)
     uint32_t few_max;           // lane-parallel intersection when at most this many lanes of a wave trace
     uint64_t* trace;            // per-wave timeline, 8 x u64 per wave (PT_TRACE kernel builds only; else nullptr)
 };

@@ -114,7 +114,7 @@ __device__ __forceinline__ void sphere_test(const f4v s, int i, V3 o, V3 d, floa
     // slower on the Cornell box and 2x slower on 4096 spheres, profiles/r1_variants.json).
     const V3 oc = v3(o.x - s.x, o.y - s.y, o.z - s.z);
     const float half_b = dot(oc, d);
-    const float c = dot(oc, oc) - s.w;
+    const float c = fmaf(oc.x, oc.x, fmaf(oc.y, oc.y, fmaf(oc.z, oc.z, -s.w)));  // |oc|^2 - r^2 in three FMAs
     const float disc = half_b * half_b - c;
     if (disc >= 0.0f) {
         if (COUNT) n_roots++;
@@ -129,7 +129,7 @@ __device__ __forceinline__ void sphere_test(const f4v s, int i, V3 o, V3 d, floa
 // dot(p - o, n) is expanded to p.n - o.n, so t = -(o.n + w) / (n.d).
 __device__ __forceinline__ void plane_test(const f4v pn, int id, V3 o, V3 d, float& tbest, int& ibest) {
     const float denom = pn.x * d.x + pn.y * d.y + pn.z * d.z;
-    const float q = pn.x * o.x + pn.y * o.y + pn.z * o.z + pn.w;
+    const float q = fmaf(pn.x, o.x, fmaf(pn.y, o.y, fmaf(pn.z, o.z, pn.w)));
     const float t = q * rcp(-denom);
     if (fabsf(denom) >= 1e-6f && t >= RAY_MIN_T && t < tbest) { tbest = t; ibest = id; }
 }
@@ -153,12 +153,12 @@ __device__ __forceinline__ void tri_test(const f4v r0, const f4v r1, const f4v r
     // the vertices on every test.  The same three numbers come out of an affine map fixed per
     // triangle (rows r0, r1, r2 = inverse of [e1 e2 n], translated by v0; built at upload in
     // double): height(x) = r2.x + r2.w vanishes on the plane, u = r0.x + r0.w, v = r1.x + r1.w.
-    const float oz = r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w;
+    const float oz = fmaf(r2.x, o.x, fmaf(r2.y, o.y, fmaf(r2.z, o.z, r2.w)));
     const float dz = r2.x * d.x + r2.y * d.y + r2.z * d.z;
     const float t = oz * rcp(-dz);  // dz == 0 (parallel, :121): inf or NaN, rejected below
     const V3 h = v3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
-    const float u = r0.x * h.x + r0.y * h.y + r0.z * h.z + r0.w;
-    const float v = r1.x * h.x + r1.y * h.y + r1.z * h.z + r1.w;
+    const float u = fmaf(r0.x, h.x, fmaf(r0.y, h.y, fmaf(r0.z, h.z, r0.w)));
+    const float v = fmaf(r1.x, h.x, fmaf(r1.y, h.y, fmaf(r1.z, h.z, r1.w)));
     const bool ok = u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t >= RAY_MIN_T && t < tbest;
     if (ok) { tbest = t; ibest = id; }
 }
@@ -306,8 +306,31 @@ __device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
 // lines: shard = blockIdx % 8 (blocks b and b+8 share an XCD under round-robin dispatch) serves
 // the 8x8 tiles congruent to it mod 8.  Two counter sets alternate between launches; each launch
 // zeroes the set of the next one (ordered by the kernel boundary), so no memset is enqueued.
+//
+// Kernel arguments.  Everything the intersection loops and the shading read stays in SGPRs for the
+// whole launch.  The camera (20 dwords) and the display-side arguments are needed only where a
+// lane starts a sample or finishes a pixel; held across the loop they pushed the kernel past the
+// 102 SGPRs a wave has and the spills (v_readlane in every loop preheader) cost more than
+// re-reading them: those are fetched from the kernarg segment, through the scalar cache, inside
+// the regeneration block (`cold()` hides the pointer from the optimiser so the loads stay there).
+struct KArgs {
+    DevSceneF sc;
+    DevCamF cam;
+    PathArgs a;
+};
+__device__ __forceinline__ const PT_CONST KArgs* cold() {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    const PT_CONST KArgs* k = (const PT_CONST KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma clang diagnostic pop
+    asm volatile("" : "+s"(k));
+    return k;
+}
+
 template <bool NEE, bool COUNT>
-__global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const DevCamF cam, const PathArgs a) {
+__global__ __launch_bounds__(256) void pt_path_kernel(const KArgs kargs) {
+    const DevSceneF& sc = kargs.sc;
+    const PathArgs& a = kargs.a;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t shard = blockIdx.x & 7u;
     const uint32_t shard_units = ((a.num_tiles + 7u - shard) >> 3) * 4u;  // 4x4 blocks of the tiles = shard (mod 8)
@@ -356,6 +379,7 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
         const uint64_t todo_mask = __ballot(todo);
         const bool regen = (uint32_t)__popcll(todo_mask) >= PT_REGEN_MIN || __ballot(alive) == 0ull;
         if (regen) {
+        const PT_CONST KArgs* kc = cold();
         // ---- (1) finished pixels are flushed: one 16-B store (the 16-B load was issued when the
         //          pixel was taken, so its latency is long gone)
         if (!alive && my >= 0 && sample_i == a.count) {
@@ -365,31 +389,33 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
             } else {  // PT_ACC_RUNNING_MEAN, renderKernel :297-304 (count == 1, s0 = frame_count)
                 acc = make_float4(sum.x, sum.y, sum.z, 1.0f);
                 if (a.s0 > 0u) {
-                    const float t = a.mean_t;
+                    const float t = kc->a.mean_t;
                     acc.x = sum.x * t + prev.x * (1.0f - t);
                     acc.y = sum.y * t + prev.y * (1.0f - t);
                     acc.z = sum.z * t + prev.z * (1.0f - t);
                 }
             }
             a.accum[pixel] = acc;
-            if (a.rgba) {  // fused convertToRGBAKernel
-                if (a.other[0]) {
+            uint32_t* const rgba = kc->a.rgba;
+            if (rgba) {  // fused convertToRGBAKernel
+                if (kc->a.other[0]) {
                     // frames in flight: the displayed mean also counts the samples the other chains hold
                     // for this pixel.  Their launches may be running, so this reads each (sum, n) either
                     // before or after their 16-B store: a consistent mean either way, display only.
                     float4 tot = acc;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        if (!a.other[k]) break;
-                        const float4 q = a.other[k][pixel];
+                        const float4* const other = kc->a.other[k];
+                        if (!other) break;
+                        const float4 q = other[pixel];
                         tot.x += q.x; tot.y += q.y; tot.z += q.z; tot.w += q.w;
                     }
                     const float inv = rcp(tot.w);
-                    a.rgba[pixel] = pack_rgba8_cuda(tot.x * inv, tot.y * inv, tot.z * inv);
+                    rgba[pixel] = pack_rgba8_cuda(tot.x * inv, tot.y * inv, tot.z * inv);
                 } else {
                     // every pixel normally holds the same count: its reciprocal comes from the host (same IEEE divide)
-                    const float inv = (a.acc_mode != 0u) ? 1.0f : (acc.w == a.total_w ? a.inv_total_w : 1.0f / acc.w);
-                    a.rgba[pixel] = pack_rgba8_cuda(acc.x * inv, acc.y * inv, acc.z * inv);
+                    const float inv = (a.acc_mode != 0u) ? 1.0f : (acc.w == kc->a.total_w ? kc->a.inv_total_w : 1.0f / acc.w);
+                    rgba[pixel] = pack_rgba8_cuda(acc.x * inv, acc.y * inv, acc.z * inv);
                 }
             }
             my = -1;
@@ -427,9 +453,9 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
                     if (tx >= (int)a.tiles_x) { tx -= (int)a.tiles_x; ty++; }
                     px = (uint32_t)tx * 8u + (q & 1u) * 4u + (li & 3u);
                     py = ty * 8u + (q >> 1) * 4u + (li >> 2);
-                    if (px < cam.width && py < cam.height) {
+                    if (px < a.width && py < a.height) {
                         my = (int)cand;
-                        pixel = py * cam.width + px;
+                        pixel = py * a.width + px;
                         pixkey = pt_hash(a.seed_hash + pixel);
                         if (need_prev) prev = a.accum[pixel];
                         sample_i = 0;
@@ -445,6 +471,7 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const DevSceneF sc, const 
             sample_i++;
             // renderKernel :286-291 + generateCameraRay :245-265:
             //   (2*(x + xi)/W - 1) * half_w  ==  (x + xi) * (2*half_w/W) - half_w
+            const PT_CONST DevCamF& cam = kc->cam;
             const float xo = ((float)px + uni(pt_draw(key, 0, 0))) * cam.sx - cam.half_w;
             const float yo = ((float)py + uni(pt_draw(key, 0, 1))) * cam.sy - cam.half_h;
             o = v3(cam.ox, cam.oy, cam.oz);
@@ -753,12 +780,15 @@ __global__ __launch_bounds__(256) void pt_valu_peak_kernel(float* sink, uint32_t
 hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArgs& a, bool nee, bool count,
                           uint32_t blocks, hipStream_t stream) {
     const dim3 grid(blocks), block(256);
+    KArgs k;
+    k.sc = sc; k.cam = cam; k.a = a;
+    k.a.width = cam.width; k.a.height = cam.height;
     if (nee) {
-        if (count) hipLaunchKernelGGL((pt_path_kernel<true, true>), grid, block, 0, stream, sc, cam, a);
-        else hipLaunchKernelGGL((pt_path_kernel<true, false>), grid, block, 0, stream, sc, cam, a);
+        if (count) hipLaunchKernelGGL((pt_path_kernel<true, true>), grid, block, 0, stream, k);
+        else hipLaunchKernelGGL((pt_path_kernel<true, false>), grid, block, 0, stream, k);
     } else {
-        if (count) hipLaunchKernelGGL((pt_path_kernel<false, true>), grid, block, 0, stream, sc, cam, a);
-        else hipLaunchKernelGGL((pt_path_kernel<false, false>), grid, block, 0, stream, sc, cam, a);
+        if (count) hipLaunchKernelGGL((pt_path_kernel<false, true>), grid, block, 0, stream, k);
+        else hipLaunchKernelGGL((pt_path_kernel<false, false>), grid, block, 0, stream, k);
     }
     return hipGetLastError();
 }
