@@ -11,7 +11,7 @@ LIB     := $(LIBDIR)/libpt_amd.so
 # (measured +15..20 % Msamples/s without it, profiles/r1_variants.json)
 KFLAGS  ?= -fno-slp-vectorize
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude
-OBJS    := build/pt_api.o build/pt_path_kernel.o build/pt_f64_kernels.o build/pt_builtin_scenes.o
+OBJS    := build/pt_api.o build/pt_path_kernel.o build/pt_f64_kernels.o build/pt_builtin_scenes.o build/pt_fly_camera.o
 
 all: $(LIB) oracle tools/pt_headless
 
@@ -36,6 +36,10 @@ build/pt_builtin_scenes.o: $(HOST)/pt_builtin_scenes.cpp include/pt_host.hpp inc
 	@mkdir -p build
 	g++ -O2 -fPIC -std=c++17 -Wall -ffp-contract=off -Iinclude -c $< -o $@
 
+build/pt_fly_camera.o: $(HOST)/pt_fly_camera.cpp include/pt.h
+	@mkdir -p build
+	g++ -O2 -fPIC -std=c++17 -Wall -ffp-contract=off -Iinclude -c $< -o $@
+
 oracle:
 	$(MAKE) -C oracle
 
@@ -53,7 +57,7 @@ clean:
 .PHONY: all oracle clean isa
 
 # kernel-variant build for A/B runs:  make variant NAME=v1 KFLAGS="-fno-slp-vectorize"
-variant: build/pt_api.o build/pt_f64_kernels.o build/pt_builtin_scenes.o
+variant: build/pt_api.o build/pt_f64_kernels.o build/pt_builtin_scenes.o build/pt_fly_camera.o
 	@mkdir -p build/var_$(NAME)
 	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -c $(CSRC)/pt_path_kernel.hip -o build/var_$(NAME)/pt_path_kernel.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libpt_amd_$(NAME).so build/pt_api.o build/var_$(NAME)/pt_path_kernel.o build/pt_f64_kernels.o build/pt_builtin_scenes.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libpt_amd_$(NAME).so build/pt_api.o build/var_$(NAME)/pt_path_kernel.o build/pt_f64_kernels.o build/pt_builtin_scenes.o build/pt_fly_camera.o

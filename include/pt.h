@@ -273,6 +273,25 @@ void launchRenderKernel(void* output_float4, uint32_t width, uint32_t height, ui
                         uint32_t grid_x, uint32_t grid_y, uint32_t grid_z,
                         uint32_t block_x, uint32_t block_y, uint32_t block_z);
 
+/* -- interactive camera (host only, no GPU needed) ---------------------------- */
+/* One iteration of the CPU app's input handling (cpu_pathtracer/src/main.cpp:157-195):
+ * yaw += dx * 0.002; pitch = clamp(pitch - dy * 0.002, -pi/2 + 0.1, pi/2 - 0.1);
+ * forward = (cos p cos y, sin p, cos p sin y); W/S along forward, A/D along
+ * normalize(forward x (0,1,0)), space / left-ctrl along +-Y, 0.1 per frame; then
+ * camera.lookAt(pos, pos + forward, (0,1,0)) (un-normalised `up`, Camera.h:251-256).
+ * Updates camera->origin/target/up/normalize_up and *yaw / *pitch.  Returns 1 when
+ * the app would reset its accumulation (any mouse motion or movement key,
+ * main.cpp:188-199: follow with pt_set_camera + pt_reset), 0 when not, < 0 on error.
+ * The X11 event pump that produces (dx, dy, keys) is out of scope; a scripted
+ * sequence replaces it (tools/pt_headless --script). */
+#define PT_KEY_W 1u
+#define PT_KEY_S 2u
+#define PT_KEY_A 4u
+#define PT_KEY_D 8u
+#define PT_KEY_SPACE 16u
+#define PT_KEY_CTRL 32u
+int pt_fly_camera_step(PtCamera* camera, double* yaw, double* pitch, double mouse_dx, double mouse_dy, uint32_t keys);
+
 /* -- built-in scenes (host only, no GPU needed) ------------------------------ */
 /* Fills *scene and *camera with pointers into storage owned by the library
  * (valid until the next call with the same name from the same thread).

@@ -58,6 +58,7 @@ using Point3d = Vec3_t;
 inline Vec3_t operator+(const Vec3_t& a, const Vec3_t& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 inline Vec3_t operator-(const Vec3_t& a, const Vec3_t& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline Vec3_t operator*(const Vec3_t& a, double t) { return {a.x * t, a.y * t, a.z * t}; }
+inline double dot(const Vec3_t& a, const Vec3_t& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline Vec3_t cross(const Vec3_t& u, const Vec3_t& v) {
     return {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
 }
@@ -151,6 +152,7 @@ public:
     virtual bool isSphere() const { return false; }
     virtual bool isPlane() const { return false; }
     virtual bool isTriangle() const { return false; }
+    virtual bool isPolygon() const { return false; }  // Rectangle_t, Tetrahedron_t: a set of triangles
 };
 
 class Sphere_t final : public ImplicitObject_t {
@@ -178,9 +180,53 @@ public:
     const Point3f_t* getVertices() const { return v_; }
     bool isTriangle() const override { return true; }
 };
+// Rectangle_t(origin, u, v, ...) (Polygon.cuh:113-168 / Polygon.h:103-153) and the tetrahedron of four
+// triangles (Tetrahedron.h:9-35, built inline in main.cu:170-200) are present in the reference's headers
+// but never reach its render loops.  Here they are composite objects: flattenSoA() emits their faces
+// as triangles that share the object's id, so the kernels need no new primitive kind.  The
+// reference's rectangle test projects the hit point on u and v separately (alpha, beta in [0,1]),
+// which describes the parallelogram only for perpendicular edges: others are rejected.
+class Polygon_t : public ImplicitObject_t {
+protected:
+    std::vector<Point3f_t> faces_;  // three vertices per triangle
+public:
+    explicit Polygon_t(Material_t* m) : ImplicitObject_t(m) {}
+    explicit Polygon_t(const Color_t& c) : ImplicitObject_t(c) {}
+    bool isPolygon() const override { return true; }
+    size_t triangleCount() const { return faces_.size() / 3; }
+    const Point3f_t* triangle(size_t i) const { return &faces_[3 * i]; }
+};
+class Rectangle_t final : public Polygon_t {
+    void build(const Point3f_t& o, const Vec3f_t& u, const Vec3f_t& v) {
+        const double uv = dot(u, v), uu = dot(u, u), vv = dot(v, v);
+        if (!(uu > 0) || !(vv > 0) || uv * uv > 1e-12 * uu * vv) throw Error(PT_ERR_INVALID, "Rectangle_t: edges must be non-zero and perpendicular");
+        const Point3f_t a = o, b = o + u, c = o + u + v, d = o + v;
+        faces_ = {a, b, c, a, c, d};  // both with normal cross(u, v), as computeNormal (Polygon.cuh:126-128)
+    }
+public:
+    Rectangle_t(const Point3f_t& origin, const Vec3f_t& u, const Vec3f_t& v, Material_t* m) : Polygon_t(m) { build(origin, u, v); }
+    Rectangle_t(const Point3d& origin, const Vec3d& u, const Vec3d& v, const ColorDBL& colour) : Polygon_t(colour) { build(origin, u, v); }
+};
+class Tetrahedron_t final : public Polygon_t {
+    void build(const Point3f_t (&p)[4]) {
+        static const int FACE[4][3] = {{0, 2, 1}, {0, 1, 3}, {1, 2, 3}, {2, 0, 3}};  // Tetrahedron.h:16-21, main.cu:183-199
+        for (auto& f : FACE) for (int k : f) faces_.push_back(p[k]);
+    }
+public:
+    Tetrahedron_t(const Point3f_t (&vertices)[4], Material_t* m) : Polygon_t(m) { build(vertices); }
+    Tetrahedron_t(const Point3f_t (&vertices)[4], const ColorDBL& colour) : Polygon_t(colour) { build(vertices); }
+    // Tetrahedron::createRegular, Tetrahedron.h:38-50
+    static Tetrahedron_t* createRegular(double radius, Material_t* m) {
+        const double a = radius * 2.0 / std::sqrt(6.0), h = radius * 3.0 / std::sqrt(6.0);
+        const Point3f_t v[4] = {{0, -radius, -h / 3}, {-a / 2, radius / 3, -h / 3}, {a / 2, radius / 3, -h / 3}, {0, 0, 2 * h / 3}};
+        return new Tetrahedron_t(v, m);
+    }
+};
 using Sphere = Sphere_t;
 using Plane = Plane_t;
 using Triangle = Triangle_t;
+using Rectangle = Rectangle_t;
+using Tetrahedron = Tetrahedron_t;
 
 // ---- camera ------------------------------------------------------------------------------
 class Camera_t {
@@ -245,6 +291,24 @@ private:
     }
 };
 using Camera = Camera_t;
+
+// The CPU app's interactive camera (cpu_pathtracer/src/main.cpp:133-205) without its X11 event pump:
+// feed it (mouse_dx, mouse_dy, key mask) per frame; `moved` tells the frame loop to reset the accumulation.
+class FlyCamera {
+    PtCamera cam_;
+    double yaw_{0.0}, pitch_{0.0};
+
+public:
+    explicit FlyCamera(const PtCamera& c) : cam_(c) {}
+    bool step(double mouse_dx, double mouse_dy, uint32_t keys) {
+        const int rc = pt_fly_camera_step(&cam_, &yaw_, &pitch_, mouse_dx, mouse_dy, keys);
+        if (rc < 0) throw Error(rc, "pt_fly_camera_step: bad arguments");
+        return rc == 1;
+    }
+    const PtCamera& camera() const { return cam_; }
+    double yaw() const { return yaw_; }
+    double pitch() const { return pitch_; }
+};
 
 // ---- scene -------------------------------------------------------------------------------
 // Owning SoA produced by SceneManager::flattenSoA(); view() is what pt_upload_scene takes.
@@ -324,6 +388,16 @@ public:
                     f.tri_v[3 * k + 2].push_back(t->getVertices()[k].z);
                 }
                 f.tri_mat.push_back(mat); f.tri_obj.push_back((uint32_t)idx);
+            } else if (o->isPolygon()) {
+                auto* g = static_cast<const Polygon_t*>(o);
+                for (size_t i = 0; i < g->triangleCount(); ++i) {
+                    for (int k = 0; k < 3; ++k) {
+                        f.tri_v[3 * k + 0].push_back(g->triangle(i)[k].x);
+                        f.tri_v[3 * k + 1].push_back(g->triangle(i)[k].y);
+                        f.tri_v[3 * k + 2].push_back(g->triangle(i)[k].z);
+                    }
+                    f.tri_mat.push_back(mat); f.tri_obj.push_back((uint32_t)idx);
+                }
             }
         }
         for (const Material_t* m : table) {

@@ -17,6 +17,7 @@ MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_GLOSSY, MAT_EMISSIVE = range(5)
 CAMERA_CUDA, CAMERA_CPU = 0, 1
 INTEGRATOR_PATH, INTEGRATOR_DIRECT = 0, 1
 FLAG_NEE_MIS, FLAG_LIGHT_COLOUR, FLAG_COUNTERS = 1, 2, 4
+KEY_W, KEY_S, KEY_A, KEY_D, KEY_SPACE, KEY_CTRL = 1, 2, 4, 8, 16, 32  # pt_fly_camera_step
 ACC_SUM, ACC_RUNNING_MEAN = 0, 1
 RESOLVE_RGBA8_CUDA, RESOLVE_RGBA8_CPU, RESOLVE_FLOAT_MEAN, RESOLVE_RGB8_PPM = range(4)
 MISS = 0xFFFFFFFF

@@ -11,7 +11,24 @@ import ctypes as C
 import numpy as np
 
 from . import _abi as abi
-from ._lib import check, lib
+from ._lib import PtError,  check, lib
+
+
+class FlyCamera:
+    """The CPU app's mouse/keyboard camera (cpu_pathtracer/src/main.cpp:157-195) driven by a script:
+    step(dx, dy, keys) updates the PtCamera and says whether the accumulation must be reset."""
+
+    def __init__(self, camera):
+        self.camera = camera
+        self.yaw = C.c_double(0.0)
+        self.pitch = C.c_double(0.0)
+
+    def step(self, mouse_dx: float = 0.0, mouse_dy: float = 0.0, keys: int = 0) -> bool:
+        rc = lib().pt_fly_camera_step(C.byref(self.camera), C.byref(self.yaw), C.byref(self.pitch),
+                                      float(mouse_dx), float(mouse_dy), int(keys))
+        if rc < 0:
+            raise PtError(rc, "pt_fly_camera_step: bad arguments")
+        return rc == 1
 
 
 def builtin_scene_from_library(name: str, width: int, height: int):

@@ -105,9 +105,34 @@ class SceneBuilder:
     def Triangle(self, v0, v1, v2, material: int) -> _Obj:
         return _Obj("triangle", (tuple(v0), tuple(v1), tuple(v2)), material)
 
+    def Rectangle(self, origin, u, v, material: int) -> _Obj:
+        """Rectangle_t(origin, u, v, ...) (Polygon.cuh:113-168): two triangles with normal cross(u, v) that share
+        the object id.  The reference's alpha/beta test describes the parallelogram only for perpendicular edges."""
+        o, u, v = (np.asarray(x, np.float64) for x in (origin, u, v))
+        if not (u @ u > 0 and v @ v > 0) or (u @ v) ** 2 > 1e-12 * (u @ u) * (v @ v):
+            raise ValueError("Rectangle: edges must be non-zero and perpendicular")
+        a, b, c, d = o, o + u, o + u + v, o + v
+        return _Obj("polygon", (tuple(map(tuple, (a, b, c))), tuple(map(tuple, (a, c, d)))), material)
+
+    def Tetrahedron(self, vertices, material: int) -> _Obj:
+        """Four triangles in the face order of Tetrahedron.h:16-21 / main.cu:183-199."""
+        p = [tuple(x) for x in vertices]
+        return _Obj("polygon", tuple((p[i], p[j], p[k]) for i, j, k in ((0, 2, 1), (0, 1, 3), (1, 2, 3), (2, 0, 3))), material)
+
+    def regular_tetrahedron(self, radius, material: int) -> _Obj:
+        """Tetrahedron::createRegular, Tetrahedron.h:38-50."""
+        a, h = radius * 2.0 / np.sqrt(6.0), radius * 3.0 / np.sqrt(6.0)
+        return self.Tetrahedron([(0, -radius, -h / 3), (-a / 2, radius / 3, -h / 3), (a / 2, radius / 3, -h / 3), (0, 0, 2 * h / 3)], material)
+
     def flatten(self) -> abi.SceneArrays:
         a = {n: [] for n, _ in abi._SCENE_FIELDS if not n.startswith("num_")}
         for idx, o in enumerate(self.objects):
+            if o.kind == "polygon":
+                for tri in o.data:
+                    for k, v in enumerate(tri):
+                        a[f"tri_v{k}x"].append(v[0]); a[f"tri_v{k}y"].append(v[1]); a[f"tri_v{k}z"].append(v[2])
+                    a["tri_mat"].append(o.mat); a["tri_obj"].append(idx)
+                continue
             if o.kind == "sphere":
                 (cx, cy, cz), r = o.data
                 a["sph_cx"].append(cx); a["sph_cy"].append(cy); a["sph_cz"].append(cz); a["sph_r"].append(r)

@@ -458,6 +458,69 @@ def test_frames_in_flight_with_bound_tensor(gpu):
         gpu.use_own_stream()
 
 
+# ------------------------------------------------------------ scripted camera (§8f.2) ---
+def test_scripted_camera_resets_accumulation_on_movement(gpu, oracle):
+    """The CPU app's frame loop (main.cpp:153-237) with a scripted input sequence: frames add up
+    while the camera rests, any movement re-aims it and restarts the accumulation."""
+    from path_tracer_amd.renderer import FlyCamera
+    sc, cam = scenes.cpu_default(160, 90)
+    p = abi.render_params(integrator=abi.INTEGRATOR_DIRECT)
+    fly = FlyCamera(cam)
+    gpu.set_scene(sc)
+    frame_count = 0
+    script = [(0, 0, 0)] * 3 + [(25.0, -10.0, abi.KEY_W)] + [(0, 0, 0)] * 2
+    for i, (dx, dy, keys) in enumerate(script):
+        if fly.step(dx, dy, keys) or i == 0:
+            gpu.set_camera(fly.camera)
+            gpu.reset()
+            frame_count = 0
+        gpu.render(frame_count, 1, p)
+        frame_count += 1
+    got = gpu.accum()
+    assert frame_count == 3 and np.all(got[..., 3] == 3)
+    # the same three frames rendered from the final camera in one go
+    gpu.set_camera(fly.camera)
+    gpu.reset()
+    gpu.render(0, 3, p)
+    np.testing.assert_allclose(got[..., :3], gpu.accum()[..., :3], rtol=1e-6, atol=1e-6)
+    # and the moved camera sees what the oracle sees from there (primary ids bit-exact)
+    ids, mats = gpu.primary_ids()
+    oid, omat = oracle.primary_ids(sc, fly.camera)
+    assert np.array_equal(ids, oid) and np.array_equal(mats, omat)
+
+
+# ------------------------------------------------- composite objects (§8f.4) on the GPU ---
+def _composite_scene(w, h):
+    from path_tracer_amd.scenes import Emissive, Lambertian, Metal, SceneBuilder
+    b = SceneBuilder()
+    white, red, mirror = b.material(Lambertian(0.73)), b.material(Lambertian((0.65, 0.05, 0.05))), b.material(Metal((0.9, 0.9, 0.9), 0.0))
+    lamp = b.material(Emissive((1.0, 0.9, 0.8), 15.0))
+    b.addObject(b.Plane((0, -2, 0), (0, 1, 0), white))
+    b.addObject(b.Plane((0, 0, -3), (0, 0, 1), white))
+    b.addObject(b.Rectangle((-1.0, 1.9, -2.0), (2.0, 0, 0), (0, 0, 1.5), lamp))      # area light facing down
+    b.addObject(b.Rectangle((-2.0, -2.0, -2.5), (0, 0, 2.0), (0, 2.5, 0), red))      # a red panel
+    b.addObject(b.Tetrahedron([(0.0, 0.2, -1.2), (-0.7, -1.0, -0.6), (0.7, -1.0, -0.6), (0.0, -1.0, -1.9)], mirror))
+    b.addObject(b.Sphere((1.2, -1.4, -1.0), 0.6, white))
+    cam = abi.make_camera((0, 0, 1.6), (0, -0.3, -1), (0, 1, 0), 70.0, w, h, abi.CAMERA_CUDA)
+    return b.flatten(), cam
+
+
+def test_composite_objects_ids_and_path(gpu, oracle):
+    sc, cam = _composite_scene(200, 120)
+    _setup(gpu, sc, cam)
+    ids, mats = gpu.primary_ids()
+    oid, omat = oracle.primary_ids(sc, cam)
+    assert np.array_equal(ids, oid) and np.array_equal(mats, omat)
+    assert {2, 3, 4} <= set(np.unique(ids).tolist())          # both rectangles and the tetrahedron are visible
+    p = abi.render_params(max_depth=12)
+    gpu.render(0, 16, p)
+    got = gpu.accum()
+    want = oracle.render_path(sc, cam, 0, 16, p, precision=32)
+    assert np.all(got[..., 3] == 16) and np.isfinite(got).all()
+    assert _frac_differing(_mean(got), _mean(want)) < 0.05
+    assert abs(_mean(got).mean() - _mean(want).mean()) < 0.01 * _mean(want).mean()
+
+
 # -------------------------------------------------------------------------- error paths ---
 def test_error_behaviour():
     from path_tracer_amd._lib import PtError

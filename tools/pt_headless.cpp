@@ -17,11 +17,14 @@ static void usage() {
     std::puts(
         "usage: pt_headless [--scene cuda_default|cpu_default|glass_stress|random4096] [--width W] [--height H]\n"
         "                   [--spp N] [--spp-per-launch K] [--max-depth D] [--integrator path|direct] [--seed S]\n"
-        "                   [--mis] [--light-colour] [--device I] [--resume raw] [--out image.ppm] [--raw accum.f32]");
+        "                   [--mis] [--light-colour] [--device I] [--resume raw] [--out image.ppm] [--raw accum.f32]\n"
+        "                   [--script camera.txt]   lines: <frames> <mouse_dx> <mouse_dy> <keys: wasd u(p) c(down) or ->\n"
+        "                                           (the CPU app's frame loop, main.cpp:153-237, 1 spp per frame;\n"
+        "                                           --out then names a printf pattern, one PPM per script line)");
 }
 
 int main(int argc, char** argv) {
-    std::string scene = "cuda_default", integrator, out, raw, resume;
+    std::string scene = "cuda_default", integrator, out, raw, resume, script;
     uint32_t W = 1280, H = 720, spp = 64, per = 0, depth = 0, seed = 0x5EED0001u, flags = 0;
     int device = 0;
     for (int i = 1; i < argc; ++i) {
@@ -41,6 +44,7 @@ int main(int argc, char** argv) {
         else if (a == "--out") out = next();
         else if (a == "--raw") raw = next();
         else if (a == "--resume") resume = next();
+        else if (a == "--script") script = next();
         else { usage(); return a == "--help" ? 0 : 2; }
     }
     try {
@@ -66,6 +70,62 @@ int main(int argc, char** argv) {
             std::fclose(f);
             pt::check(pt_upload_accum(r.ctx(), acc.data(), acc.size() * 4));
             begin = (uint32_t)acc[3];
+        }
+        if (!script.empty()) {
+            // The CPU app's frame loop (main.cpp:153-237) fed from a file instead of X11 events: one
+            // sample per pixel per frame; any mouse motion or movement key re-aims the camera and
+            // resets the accumulation (:196-205); frame_count counts frames since the last reset.
+            FILE* f = std::fopen(script.c_str(), "r");
+            if (!f) { std::fprintf(stderr, "cannot read %s\n", script.c_str()); return 1; }
+            pt::FlyCamera fly(c);
+            uint32_t frame_count = 0, total = 0, line = 0, resets = 0;
+            unsigned frames; double dx, dy; char keys[32];
+            r.sync();
+            auto t0 = std::chrono::steady_clock::now();
+            while (std::fscanf(f, "%u %lf %lf %31s", &frames, &dx, &dy, keys) == 4) {
+                uint32_t mask = 0;
+                for (const char* k = keys; *k; ++k)
+                    mask |= *k == 'w' ? PT_KEY_W : *k == 's' ? PT_KEY_S : *k == 'a' ? PT_KEY_A : *k == 'd' ? PT_KEY_D
+                          : *k == 'u' ? PT_KEY_SPACE : *k == 'c' ? PT_KEY_CTRL : 0u;
+                for (unsigned i = 0; i < frames; ++i) {
+                    if (fly.step(dx, dy, mask)) {
+                        r.setCamera(fly.camera());
+                        pt::check(pt_reset(r.ctx()));
+                        frame_count = 0; ++resets;
+                    } else if (total == 0) {
+                        r.setCamera(fly.camera());  // the loop's first lookAt re-aims the camera even without input (:168)
+                    }
+                    r.render(frame_count, 1, p);
+                    ++frame_count; ++total;
+                }
+                if (!out.empty()) {
+                    char name[512];
+                    std::snprintf(name, sizeof name, out.c_str(), line);
+                    r.resolve(PT_RESOLVE_RGB8_PPM);
+                    std::vector<unsigned char> img(npix * 3);
+                    r.readback(img.data(), img.size());
+                    FILE* o = std::fopen(name, "wb");
+                    if (!o) { std::fprintf(stderr, "cannot write %s\n", name); return 1; }
+                    std::fprintf(o, "P6\n%u %u\n255\n", W, H);
+                    std::fwrite(img.data(), 1, img.size(), o);
+                    std::fclose(o);
+                }
+                ++line;
+            }
+            std::fclose(f);
+            r.sync();
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("{\"scene\": \"%s\", \"script_lines\": %u, \"frames\": %u, \"resets\": %u, \"frames_since_reset\": %u, "
+                        "\"seconds\": %.6f, \"fps\": %.2f}\n", scene.c_str(), line, total, resets, frame_count, sec, total / sec);
+            if (!raw.empty()) {
+                std::vector<float> acc(npix * 4);
+                r.readbackAccum(acc.data(), acc.size() * 4);
+                FILE* o = std::fopen(raw.c_str(), "wb");
+                if (!o) { std::fprintf(stderr, "cannot write %s\n", raw.c_str()); return 1; }
+                std::fwrite(acc.data(), 4, acc.size(), o);
+                std::fclose(o);
+            }
+            return 0;
         }
         r.sync();
         auto t0 = std::chrono::steady_clock::now();
