@@ -125,7 +125,9 @@ typedef struct PtCamera {
     double focus_dist;
     uint32_t width;
     uint32_t height;
-    uint32_t use_dof;      /* carried for shape; the render loops never use DOF */
+    uint32_t use_dof;      /* 1 = thin-lens rays (Camera_t::getRayDevice, Camera.cu:31-47) in the path integrator:
+                              lens radius aperture/2, screen at focus_dist.  The reference's render loops never
+                              set it; the direct integrator and the id pass ignore it. */
     uint32_t model;        /* PT_CAMERA_CUDA | PT_CAMERA_CPU */
     uint32_t normalize_up; /* 1 = constructor behaviour */
 } PtCamera;

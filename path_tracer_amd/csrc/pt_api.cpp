@@ -453,6 +453,7 @@ int pt_set_camera(PtContext* ctx, const PtCamera* c) {
     if (c->model == PT_CAMERA_CPU && (c->width < 2 || c->height < 2))
         return fail(PT_ERR_INVALID, "the CPU camera divides by (width-1) and (height-1)");
     if (!(c->fov_deg > 0.0 && c->fov_deg < 180.0)) return fail(PT_ERR_INVALID, "fov must be in (0,180) degrees");
+    if (c->use_dof && !(c->aperture >= 0.0 && c->focus_dist > 0.0)) return fail(PT_ERR_INVALID, "depth of field needs aperture >= 0 and focus_dist > 0");
     if (int rc = alloc_frame(ctx, c->width, c->height)) return rc;
 
     // ---- Camera_t::initialize (Camera.cu:3-23), float; initializeGPUData (raytracer_kernel.cu:308-321)
@@ -475,6 +476,8 @@ int pt_set_camera(PtContext* ctx, const PtCamera* c) {
     cf.half_w = vw * 0.5f; cf.half_h = vh * 0.5f;
     cf.sx = 2.0f * cf.half_w / (float)c->width; cf.sy = 2.0f * cf.half_h / (float)(int)c->height;
     cf.width = c->width; cf.height = c->height;
+    cf.lens_radius = c->use_dof ? (float)c->aperture / 2.0f : 0.0f;  // Camera.cu:20
+    cf.focus_dist = (float)c->focus_dist;
 
     DevCamD& cd = ctx->cd;
     memset(&cd, 0, sizeof cd);

@@ -39,6 +39,8 @@ struct DevCamF {
     float ux, uy, uz;  // up      =  v
     float half_w, half_h;
     float sx, sy;      // 2*half_w/width, 2*half_h/height
+    float lens_radius; // aperture / 2 when use_dof (Camera.cu:20), else 0 = pinhole
+    float focus_dist;
     uint32_t width, height;
 };
 

@@ -475,8 +475,21 @@ __global__ __launch_bounds__(256) void pt_path_kernel(const KArgs kargs) {
             const float xo = ((float)px + uni(pt_draw(key, 0, 0))) * cam.sx - cam.half_w;
             const float yo = ((float)py + uni(pt_draw(key, 0, 1))) * cam.sy - cam.half_h;
             o = v3(cam.ox, cam.oy, cam.oz);
-            d = normalized(v3(cam.fx + cam.rx * xo + cam.ux * yo, cam.fy + cam.ry * xo + cam.uy * yo,
-                              cam.fz + cam.rz * xo + cam.uz * yo));
+            d = v3(cam.fx + cam.rx * xo + cam.ux * yo, cam.fy + cam.ry * xo + cam.uy * yo, cam.fz + cam.rz * xo + cam.uz * yo);
+            const float lens_radius = cam.lens_radius;
+            if (lens_radius > 0.0f) {  // wave-uniform
+                // Depth of field, Camera_t::getRayDevice (Camera.cu:31-47): the virtual screen is at focus_dist
+                // (Camera.cu:15-19), the origin moves on the lens disk (randomInUnitDisk, :25-29) in the
+                // camera's right/up plane and the ray aims at the point the pinhole ray reaches on that screen.
+                const float r = fsqrt(uni(pt_draw(key, 0, 2))) * lens_radius;
+                const float th = uni(pt_draw(key, 0, 3));
+                const float lx = r * cos2pi(th), ly = r * sin2pi(th);
+                const V3 org = v3(o.x + cam.rx * lx + cam.ux * ly, o.y + cam.ry * lx + cam.uy * ly, o.z + cam.rz * lx + cam.uz * ly);
+                const float fd = cam.focus_dist;
+                d = v3(o.x + d.x * fd - org.x, o.y + d.y * fd - org.y, o.z + d.z * fd - org.z);
+                o = org;
+            }
+            d = normalized(d);
             beta = v3(1, 1, 1);
             L = v3(0, 0, 0);
             depth = 0;

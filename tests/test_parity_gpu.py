@@ -521,6 +521,30 @@ def test_composite_objects_ids_and_path(gpu, oracle):
     assert abs(_mean(got).mean() - _mean(want).mean()) < 0.01 * _mean(want).mean()
 
 
+# ------------------------------------------------------- depth of field (§8f.4) ---
+def test_depth_of_field_matches_oracle(gpu, oracle):
+    """Thin-lens camera rays (Camera_t::getRayDevice, Camera.cu:31-47) in the path integrator."""
+    sc, cam = scenes.cuda_default(240, 135)
+    p = abi.render_params(max_depth=8)
+    _setup(gpu, sc, cam)
+    gpu.render(0, 16, p)
+    pinhole = gpu.accum()
+    cam.use_dof, cam.aperture, cam.focus_dist = 1, 0.0, 2.6      # a zero aperture is the pinhole camera, bit for bit
+    _setup(gpu, sc, cam)
+    gpu.render(0, 16, p)
+    assert np.array_equal(gpu.accum(), pinhole)
+    cam.aperture = 0.4
+    _setup(gpu, sc, cam)
+    gpu.render(0, 16, p)
+    got = gpu.accum()
+    want = oracle.render_path(sc, cam, 0, 16, p, precision=32)
+    assert np.all(got[..., 3] == 16) and np.isfinite(got).all()
+    assert _frac_differing(_mean(got), _mean(want)) < 0.05
+    # it is a different image from the pinhole one (edges blur) with the same overall brightness
+    assert np.abs(_mean(got) - _mean(pinhole)).mean() > 0.01
+    assert abs(_mean(got).mean() - _mean(pinhole).mean()) < 0.05 * _mean(pinhole).mean()
+
+
 # -------------------------------------------------------------------------- error paths ---
 def test_error_behaviour():
     from path_tracer_amd._lib import PtError
