@@ -327,8 +327,14 @@ __device__ __forceinline__ const PT_CONST KArgs* cold() {
     return k;
 }
 
+#ifdef PT_WAVES_PER_EU  // occupancy experiments (make variant KFLAGS=-DPT_WAVES_PER_EU=7)
+#define PT_OCC __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU, PT_WAVES_PER_EU)))
+#else
+#define PT_OCC
+#endif
+
 template <bool NEE, bool COUNT>
-__global__ __launch_bounds__(256) void pt_path_kernel(const KArgs kargs) {
+__global__ __launch_bounds__(256) PT_OCC void pt_path_kernel(const KArgs kargs) {
     const DevSceneF& sc = kargs.sc;
     const PathArgs& a = kargs.a;
     const uint32_t lane = threadIdx.x & 63u;
