@@ -545,6 +545,79 @@ def test_depth_of_field_matches_oracle(gpu, oracle):
     assert abs(_mean(got).mean() - _mean(pinhole).mean()) < 0.05 * _mean(pinhole).mean()
 
 
+# ------------------------------------------------ general planes, empty and degenerate scenes ---
+def _tilted_scene(w, h):
+    """Planes whose normals are not axis-aligned (the general plane test), one degenerate normal,
+    more than four of them (two loop trips), and a sphere light."""
+    from path_tracer_amd.scenes import Emissive, Glossy, Lambertian, Metal, SceneBuilder
+    b = SceneBuilder()
+    white, green, mirror = b.material(Lambertian(0.73)), b.material(Lambertian((0.12, 0.45, 0.15))), b.material(Metal((0.8, 0.8, 0.9), 0.1))
+    gloss, lamp = b.material(Glossy((0.9, 0.6, 0.2), 0.3, 0.8)), b.material(Emissive((1, 1, 1), 15.0))
+    b.addObject(b.Plane((0, -2, 0), (0.1, 1.0, 0.05), white))          # tilted floor
+    b.addObject(b.Plane((0, 0, -4), (0.2, -0.1, 1.0), white))          # tilted back wall
+    b.addObject(b.Plane((-2.5, 0, 0), (1.0, 0.15, 0.1), green))        # tilted left wall
+    b.addObject(b.Plane((2.5, 0, 0), (-1.0, 0.1, -0.2), mirror))       # tilted mirror wall
+    b.addObject(b.Plane((0, 3, 0), (0.05, -1.0, 0.1), white))          # tilted ceiling
+    b.addObject(b.Plane((0, 0, 0), (0.0, 0.0, 0.0), green))            # degenerate normal: can never be hit
+    b.addObject(b.Plane((0, 0, 3), (0, 0, -1), white))                 # one axis-aligned plane among them
+    b.addObject(b.Sphere((0.3, -1.2, -1.5), 0.7, gloss))
+    b.addObject(b.Sphere((0, 2.2, -1.5), 0.4, lamp).makeEmissive((1, 1, 1), 15.0))
+    cam = abi.make_camera((0, 0, 1.6), (0, -0.2, -1), (0, 1, 0), 75.0, w, h, abi.CAMERA_CUDA)
+    return b.flatten(), cam
+
+
+@pytest.mark.parametrize("flags", [0, abi.FLAG_NEE_MIS])
+def test_general_planes_ids_and_path(gpu, oracle, flags):
+    sc, cam = _tilted_scene(192, 108)
+    _setup(gpu, sc, cam)
+    ids, mats = gpu.primary_ids()
+    oid, omat = oracle.primary_ids(sc, cam)
+    assert np.array_equal(ids, oid) and np.array_equal(mats, omat)
+    assert 5 not in set(np.unique(ids).tolist())               # the degenerate plane is never seen
+    p = abi.render_params(max_depth=10, flags=flags)
+    gpu.render(0, 16, p)
+    got = gpu.accum()
+    want = oracle.render_path(sc, cam, 0, 16, p, precision=32)
+    assert np.all(got[..., 3] == 16) and np.isfinite(got).all()
+    assert _frac_differing(_mean(got), _mean(want)) < 0.05
+    assert abs(_mean(got).mean() - _mean(want).mean()) < 0.01 * _mean(want).mean()
+
+
+def test_empty_and_lightless_scenes(gpu, oracle):
+    from path_tracer_amd.scenes import Lambertian, SceneBuilder
+    # no primitives at all is refused at upload with a clear error (nothing to render)
+    from path_tracer_amd._lib import PtError
+    b = SceneBuilder()
+    b.material(Lambertian(0.5))
+    cam = abi.make_camera((0, 0, 1.6), (0, 0, -1), (0, 1, 0), 90.0, 64, 36, abi.CAMERA_CUDA)
+    with pytest.raises(PtError, match="at least one primitive"):
+        gpu.set_scene(b.flatten())
+    # a scene nobody looks at: every ray misses, the image is black, ids are all MISS
+    b = SceneBuilder()
+    b.addObject(b.Sphere((0, 0, 50.0), 0.5, b.material(Lambertian(0.5))))
+    sc = b.flatten()
+    _setup(gpu, sc, cam)
+    ids, _ = gpu.primary_ids()
+    assert np.all(ids == abi.MISS)
+    for flags in (0, abi.FLAG_NEE_MIS):
+        gpu.reset()
+        gpu.render(0, 3, abi.render_params(flags=flags))
+        acc = gpu.accum()
+        assert np.all(acc[..., 3] == 3) and not acc[..., :3].any()
+    # geometry but no light: light sampling has nothing to pick, the image stays black and finite
+    b = SceneBuilder()
+    m = b.material(Lambertian(0.5))
+    b.addObject(b.Plane((0, -1, 0), (0, 1, 0), m))
+    b.addObject(b.Sphere((0, 0, -2), 0.8, m))
+    sc = b.flatten()
+    _setup(gpu, sc, cam)
+    gpu.render(0, 4, abi.render_params(flags=abi.FLAG_NEE_MIS, max_depth=6))
+    acc = gpu.accum()
+    assert np.all(acc[..., 3] == 4) and not acc[..., :3].any()
+    want = oracle.render_path(sc, cam, 0, 4, abi.render_params(flags=abi.FLAG_NEE_MIS, max_depth=6), precision=32)
+    assert not want[..., :3].any()
+
+
 # -------------------------------------------------------------------------- error paths ---
 def test_error_behaviour():
     from path_tracer_amd._lib import PtError
