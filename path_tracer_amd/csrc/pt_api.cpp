@@ -83,6 +83,10 @@ struct PtContext {
     uint64_t* trace = nullptr;         // PT_AMD_TRACE=<file>: per-wave timeline of the last launch (PT_TRACE kernel builds)
     size_t trace_waves = 0;
     uint32_t resident_blocks[4] = {0, 0, 0, 0};  // per kernel variant (nee, count)
+    // tuning / tracing knobs for tools/gpu_ab.py and tools/gpu_trace.py, read once at pt_create
+    // (PT_AMD_FEW_MAX, PT_AMD_MAX_BLOCKS, PT_AMD_TRACE); -1 / empty = not set
+    int knob_few_max = -1, knob_max_blocks = -1;
+    std::string knob_trace;
 };
 
 namespace {
@@ -204,6 +208,9 @@ int pt_create(int device_id, PtContext** out) {
     PtContext* ctx = new (std::nothrow) PtContext();
     if (!ctx) return fail(PT_ERR_INVALID, "out of host memory");
     ctx->device = device_id;
+    if (const char* e = getenv("PT_AMD_FEW_MAX")) ctx->knob_few_max = atoi(e);
+    if (const char* e = getenv("PT_AMD_MAX_BLOCKS")) ctx->knob_max_blocks = atoi(e);
+    if (const char* e = getenv("PT_AMD_TRACE")) ctx->knob_trace = e;
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(PT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     ctx->stream = ctx->own_stream;
@@ -558,7 +565,7 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
         return fail(PT_ERR_INVALID, "the running-mean mode adds one sample per launch, like renderKernel");
     // frames in flight: sums only (a running mean is a recurrence on one buffer), and not while
     // a per-launch trace is being written
-    const bool pipelined = ctx->flight > 1 && prm->acc_mode == PT_ACC_SUM && !getenv("PT_AMD_TRACE");
+    const bool pipelined = ctx->flight > 1 && prm->acc_mode == PT_ACC_SUM && ctx->knob_trace.empty();
     uint32_t chain = 0;
     hipStream_t stream = ctx->stream;
     if (pipelined) {
@@ -618,15 +625,15 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
         const uint32_t per_ray = 40u + 27u * (((uint32_t)f.ns + 63u) / 64u) + 15u * (((uint32_t)f.np + 63u) / 64u) + 37u * (((uint32_t)f.nt + 63u) / 64u);
         uint32_t few = serial / per_ray;
         a.few_max = few > 48u ? 48u : few;
-        if (const char* e = getenv("PT_AMD_FEW_MAX")) a.few_max = (uint32_t)atoi(e);  // tuning experiments
+        if (ctx->knob_few_max >= 0) a.few_max = (uint32_t)ctx->knob_few_max;
     }
-    if (const char* e = getenv("PT_AMD_MAX_BLOCKS")) { const uint32_t m = (uint32_t)atoi(e); if (m && blocks > m) blocks = m; }  // tuning experiments
+    if (ctx->knob_max_blocks > 0 && blocks > (uint32_t)ctx->knob_max_blocks) blocks = (uint32_t)ctx->knob_max_blocks;
     if (blocks < 8u) blocks = 8u;                            // every shard needs a block to serve its tiles
     // launches of one chain are ordered on its stream (chain 0 also serves unpipelined launches, which
     // join_chains() orders after it): each zeroes the set its successor on the same chain will use
     a.work_counter = ctx->work_counter + WORK_SET_WORDS * (2u * chain + ctx->work_parity[chain]);
     a.next_counter = ctx->work_counter + WORK_SET_WORDS * (2u * chain + (ctx->work_parity[chain] ^ 1u));
-    const char* trace_file = getenv("PT_AMD_TRACE");  // kernel-timeline experiments (tools/gpu_trace.py)
+    const char* trace_file = ctx->knob_trace.empty() ? nullptr : ctx->knob_trace.c_str();  // kernel-timeline experiments (tools/gpu_trace.py)
     if (trace_file) {
         const size_t waves = (size_t)blocks * 4u;
         if (ctx->trace_waves < waves) {

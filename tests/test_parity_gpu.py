@@ -645,6 +645,48 @@ def test_gpu_against_committed_golden_frames(gpu):
     assert abs(got[..., :3].mean() - want[..., :3].mean()) < 0.05 * want[..., :3].mean()
 
 
+# --------------------------------------------- headless driver and file formats (§8f.3) ---
+def test_headless_driver_ppm_checkpoint_resume_and_script(tmp_path):
+    """tools/pt_headless (C++ host over the C ABI): P6 output, raw (sum, count) checkpoint, resume, scripted camera."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "pt_headless")
+    W, H = 96, 54
+
+    def run(*args):
+        out = subprocess.run([exe, "--scene", "cuda_default", "--width", str(W), "--height", str(H), *args],
+                             check=True, capture_output=True, text=True, timeout=120).stdout
+        return json.loads(out.strip().splitlines()[-1])
+
+    full, half, rest = tmp_path / "full.f32", tmp_path / "half.f32", tmp_path / "rest.f32"
+    ppm = tmp_path / "frame.ppm"
+    info = run("--spp", "8", "--spp-per-launch", "4", "--raw", str(full), "--out", str(ppm))
+    assert info["spp"] == 8 and info["width"] == W
+    data = ppm.read_bytes()
+    header = f"P6\n{W} {H}\n255\n".encode()
+    assert data.startswith(header) and len(data) == len(header) + 3 * W * H      # Camera::saveImage layout, Camera.h:162-180
+    a = np.fromfile(full, np.float32).reshape(H, W, 4)
+    assert np.all(a[..., 3] == 8)
+    # the PPM is the gamma-2.2, +0.5-rounded mean of the same buffer (Color.h:86-91)
+    img = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3).astype(int)
+    want = (np.clip(np.maximum(a[..., :3] / 8.0, 0.0) ** (1.0 / 2.2), 0.0, 1.0) * 255.0 + 0.5).astype(int)
+    assert np.abs(img - want).max() <= 1
+    # 4 spp, checkpoint, resume for 4 more == 8 spp in one go, bit for bit
+    run("--spp", "4", "--spp-per-launch", "4", "--raw", str(half))
+    run("--spp", "4", "--spp-per-launch", "4", "--resume", str(half), "--raw", str(rest))
+    assert np.array_equal(np.fromfile(rest, np.float32), np.fromfile(full, np.float32))
+    # scripted camera: 2 frames at rest, 1 moving (resets), 3 at rest -> 4 frames in the buffer
+    script = tmp_path / "moves.txt"
+    script.write_text("2 0 0 -\n1 15 -5 wd\n3 0 0 -\n")
+    acc = tmp_path / "fly.f32"
+    info = run("--script", str(script), "--raw", str(acc), "--out", str(tmp_path / "fly_%02u.ppm"))
+    assert info["frames"] == 6 and info["resets"] == 1 and info["frames_since_reset"] == 4
+    assert np.all(np.fromfile(acc, np.float32).reshape(H, W, 4)[..., 3] == 4)
+    assert all((tmp_path / f"fly_{i:02d}.ppm").exists() for i in range(3))
+
+
 # -------------------------------------------------------------------------- error paths ---
 def test_error_behaviour():
     from path_tracer_amd._lib import PtError
