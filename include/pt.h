@@ -245,6 +245,16 @@ int pt_readback_accum(PtContext* ctx, float* host_dst, size_t bytes);
 int pt_upload_accum(PtContext* ctx, const float* host_src, size_t bytes);
 int pt_sync(PtContext* ctx);
 
+/* Multi-GPU: every rank holds the whole frame and renders its own sample indices;
+ * this adds the accumulation buffers (sums and counts) of all ranks of an existing RCCL
+ * communicator in place — ncclReduce to `root`, or ncclAllReduce when root < 0 — on the
+ * context's stream, after folding the frames in flight.  `nccl_comm` is the caller's
+ * ncclComm_t (one process per GPU, created by the host with ncclCommInitRank).  The library
+ * does not link RCCL: it resolves ncclReduce / ncclAllReduce from the copy already loaded in the
+ * process (the one that made the communicator), falling back to librccl.so.1.  Asynchronous.
+ * (The reference is single-GPU, main.cu:30; no counterpart.) */
+int pt_reduce(PtContext* ctx, void* nccl_comm, int root);
+
 /* Device pointers for callers that drive collectives themselves. */
 void* pt_accum_device_ptr(PtContext* ctx);
 void* pt_display_device_ptr(PtContext* ctx);

@@ -9,6 +9,8 @@
 #include "../../include/pt.h"
 #include "pt_device.h"
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -724,6 +726,35 @@ int pt_sync(PtContext* ctx) {
     if (int rc = use(ctx)) return rc;
     if (int rc = join_chains(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_reduce(PtContext* ctx, void* nccl_comm, int root) {
+    if (int rc = use(ctx)) return rc;
+    if (!nccl_comm) return fail(PT_ERR_INVALID, "communicator is null");
+    if (!ctx->accum) return fail(PT_ERR_STATE, "no frame allocated");
+    // ncclResult_t ncclReduce(send, recv, count, datatype, op, root, comm, stream); ncclAllReduce without root
+    using reduce_fn = int (*)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
+    using allreduce_fn = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static void* fn_reduce = nullptr;
+    static void* fn_allreduce = nullptr;
+    if (!fn_reduce || !fn_allreduce) {
+        fn_reduce = dlsym(RTLD_DEFAULT, "ncclReduce");
+        fn_allreduce = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        if (!fn_reduce || !fn_allreduce) {
+            if (void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL)) {
+                fn_reduce = dlsym(h, "ncclReduce");
+                fn_allreduce = dlsym(h, "ncclAllReduce");
+            }
+        }
+        if (!fn_reduce || !fn_allreduce) return fail(PT_ERR_STATE, "RCCL is not loaded in this process (ncclReduce / ncclAllReduce not found)");
+    }
+    if (int rc = join_chains(ctx)) return rc;
+    const size_t count = (size_t)ctx->width * ctx->height * 4u;
+    const int nccl_float = 7, nccl_sum = 0;  // ncclFloat32, ncclSum (rccl.h)
+    const int res = root >= 0 ? ((reduce_fn)fn_reduce)(ctx->accum, ctx->accum, count, nccl_float, nccl_sum, root, nccl_comm, ctx->stream)
+                              : ((allreduce_fn)fn_allreduce)(ctx->accum, ctx->accum, count, nccl_float, nccl_sum, nccl_comm, ctx->stream);
+    if (res != 0) return fail(PT_ERR_HIP, "RCCL %s failed with ncclResult_t %d", root >= 0 ? "ncclReduce" : "ncclAllReduce", res);
     return PT_OK;
 }
 

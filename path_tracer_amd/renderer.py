@@ -81,6 +81,10 @@ class Renderer:
         """1..4 consecutive sum-mode launches overlap on internal streams (include/pt.h)."""
         check(self._L.pt_set_frames_in_flight(self._ctx, n))
 
+    def reduce(self, nccl_comm, root: int = 0):
+        """In-place RCCL sum of the accumulation buffer over the communicator's ranks (root < 0: all-reduce)."""
+        check(self._L.pt_reduce(self._ctx, C.c_void_p(nccl_comm), int(root)))
+
     def flush(self):
         """Fold the in-flight chains into the accumulation buffer (asynchronous)."""
         check(self._L.pt_flush(self._ctx))

@@ -687,6 +687,45 @@ def test_headless_driver_ppm_checkpoint_resume_and_script(tmp_path):
     assert all((tmp_path / f"fly_{i:02d}.ppm").exists() for i in range(3))
 
 
+# ------------------------------------------------------------- native RCCL reduce ---
+def test_pt_reduce_on_a_one_rank_communicator(gpu):
+    """pt_reduce hands the accumulation buffer to ncclReduce / ncclAllReduce of the RCCL copy loaded in the
+    process.  One GPU here, so the communicator has one rank and the sum is the buffer itself; the
+    N-rank arithmetic is covered by the 2-rank gloo test on the CPU and by bench.py --gpus N."""
+    import glob
+    import os
+    import torch
+    from path_tracer_amd._lib import PtError
+    path = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*"))[0]
+    rccl = C.CDLL(path, mode=C.RTLD_GLOBAL)       # the copy torch uses; global, so the library's dlsym sees it
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid, comm = UniqueId(), C.c_void_p()
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    torch.cuda.set_device(0)
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        sc, cam = scenes.cuda_default(160, 90)
+        _setup(gpu, sc, cam)
+        gpu.set_frames_in_flight(2)
+        for s in range(4):
+            gpu.render(s, 1, abi.render_params())
+        gpu.reduce(comm.value, root=0)          # folds the chains, then ncclReduce in place
+        after = gpu.accum()
+        assert np.all(after[..., 3] == 4)
+        gpu.reduce(comm.value, root=-1)         # ncclAllReduce
+        assert np.array_equal(gpu.accum(), after)
+        with pytest.raises(PtError, match="communicator is null"):
+            gpu.reduce(None, 0)
+    finally:
+        gpu.set_frames_in_flight(1)
+        rccl.ncclCommDestroy(comm)
+
+
 # -------------------------------------------------------------------------- error paths ---
 def test_error_behaviour():
     from path_tracer_amd._lib import PtError
