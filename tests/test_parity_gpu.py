@@ -411,6 +411,43 @@ def test_frames_in_flight_match_serial(gpu, n):
         gpu.set_frames_in_flight(1)
 
 
+def test_frames_in_flight_random_call_sequences(gpu):
+    """Any interleaving of renders with the calls that read, replace or re-target the accumulation buffer keeps
+    the books: the buffer always holds exactly the samples rendered since the last reset, each once."""
+    rng = np.random.default_rng(20261110)
+    sc, cam = scenes.cuda_default(96, 54)
+    sc2, cam2 = scenes.glass_stress(96, 54)
+    _setup(gpu, sc, cam)
+    expected = 0      # samples per pixel the buffer must hold
+    next_sample = 0
+    try:
+        for step in range(300):
+            op = rng.integers(0, 12)
+            if op <= 4:
+                n = int(rng.integers(1, 4))
+                gpu.render(next_sample, n, abi.render_params(fused_rgba8=int(rng.integers(0, 2)), max_depth=6))
+                next_sample += n; expected += n
+            elif op == 5:
+                gpu.set_frames_in_flight(int(rng.integers(1, 5)))
+            elif op == 6:
+                gpu.flush()
+            elif op == 7:
+                acc = gpu.accum()
+                assert np.all(acc[..., 3] == expected), (step, expected)
+            elif op == 8:
+                gpu.reset(); expected = 0
+            elif op == 9:
+                gpu.resolve(abi.RESOLVE_RGBA8_CUDA)
+            elif op == 10:
+                gpu.set_camera(cam2 if rng.integers(0, 2) else cam)        # same size: keeps the samples
+            else:
+                gpu.set_scene(sc2 if rng.integers(0, 2) else sc)
+        acc = gpu.accum()
+        assert np.all(acc[..., 3] == expected) and np.isfinite(acc).all()
+    finally:
+        gpu.set_frames_in_flight(1)
+
+
 def test_frames_in_flight_full_size_and_reset(gpu):
     sc, cam = scenes.cuda_default(1280, 720)
     _setup(gpu, sc, cam)
