@@ -20,10 +20,14 @@
  * PARITY PIN: the reference CPU program cannot be built in this image
  * (cpu_pathtracer/include/Vec3.h:5 needs <format>, absent from g++ 11.4, and no
  * stand-in header may be written), and the reference holds no tests or golden
- * vectors.  The only known answers are the two primary-hit histograms recorded
- * in BASELINE.md §2 / SURVEY.md §8c; tests/test_oracle_pins.py checks the
- * `direct`-side restatement (camera + Scene::intersect) against both.  Everything
- * else is "parity unpinned".
+ * vectors.  The known answers are (1) the two primary-hit histograms recorded
+ * in BASELINE.md §2 / SURVEY.md §8c: tests/test_oracle_pins.py checks the
+ * `direct`-side restatement (camera + Scene::intersect) against both; (2) the one
+ * output of the CUDA program the reference holds, images/cuda.png (a screenshot of
+ * its default scene): the `path` restatement reproduces it to a few 8-bit levels
+ * (fixture tests/golden/reference_cuda_screenshot_480x270.npz).  That is an
+ * image-level pin (8 bits, unknown sample count); individual formulas of the `path`
+ * integrator and the `direct` light term remain "parity unpinned" beyond it.
  */
 #ifndef PT_ORACLE_H_
 #define PT_ORACLE_H_

@@ -655,6 +655,30 @@ def test_empty_and_lightless_scenes(gpu, oracle):
     assert not want[..., :3].any()
 
 
+# ------------------------------------------- the reference's own published render ---
+def test_path_against_the_references_own_render(gpu):
+    """images/cuda.png of the reference (a screenshot of the CUDA app: default scene, 1920x1080 client area, unknown
+    sample count, 8 bits, truncated) as the fixture tests/golden/reference_cuda_screenshot_480x270.npz.  Same
+    scene, camera, resolution; 1024 samples; clamp as convertToRGBAKernel does; 4x4 box filter like the fixture.
+    Measured: MAE 0.011 (2.8 of 255 levels), channel means +0.5...+1.3 % (0.8 % of that is the screenshot's
+    truncation to 8 bits)."""
+    import os
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_cuda_screenshot_480x270.npz"))["rgb"].astype(np.float64) / 255.0
+    sc, cam = scenes.cuda_default(1920, 1080)
+    for flags in (0, abi.FLAG_NEE_MIS):             # the MIS estimator has the same expectation
+        _setup(gpu, sc, cam)
+        for s0 in range(0, 1024, 64):
+            gpu.render(s0, 64, abi.render_params(flags=flags))
+        acc = gpu.accum()
+        disp = np.clip(acc[..., :3] / acc[..., 3:4], 0.0, 1.0).astype(np.float64)
+        small = disp.reshape(270, 4, 480, 4, 3).mean(axis=(1, 3))
+        d = np.abs(small - ref)
+        assert d.mean() < 0.02, d.mean()
+        assert np.sqrt((d ** 2).mean()) < 0.05
+        assert np.all(np.abs(small.mean(axis=(0, 1)) / ref.mean(axis=(0, 1)) - 1.0) < 0.025)
+        assert np.abs(small[:, ::-1] - ref).mean() > 0.1   # the mirrored image does not match
+
+
 # ----------------------------------------------------- committed golden fixtures ---
 def test_gpu_against_committed_golden_frames(gpu):
     """The HIP path against tests/golden/oracle_frames.npz (written by tests/golden/make_golden.py from the
