@@ -435,6 +435,9 @@ public:
     void readback(void* dst, size_t bytes) { check(pt_readback(ctx_, dst, bytes)); }
     void readbackAccum(float* dst, size_t bytes) { check(pt_readback_accum(ctx_, dst, bytes)); }
     void sync() { check(pt_sync(ctx_)); }
+    void setFramesInFlight(uint32_t n) { check(pt_set_frames_in_flight(ctx_, n)); }  // overlap consecutive launches (pt.h)
+    void flush() { check(pt_flush(ctx_)); }
+    void reduce(void* nccl_comm, int root) { check(pt_reduce(ctx_, nccl_comm, root)); }  // multi-GPU sum, one process per GPU
 };
 
 inline PtRenderParams defaultParams() {

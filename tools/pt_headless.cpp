@@ -18,6 +18,7 @@ static void usage() {
         "usage: pt_headless [--scene cuda_default|cpu_default|glass_stress|random4096] [--width W] [--height H]\n"
         "                   [--spp N] [--spp-per-launch K] [--max-depth D] [--integrator path|direct] [--seed S]\n"
         "                   [--mis] [--light-colour] [--device I] [--resume raw] [--out image.ppm] [--raw accum.f32]\n"
+        "                   [--frames-in-flight 1..4]  overlap consecutive launches (progressive rendering at few spp per launch)\n"
         "                   [--script camera.txt]   lines: <frames> <mouse_dx> <mouse_dy> <keys: wasd u(p) c(down) or ->\n"
         "                                           (the CPU app's frame loop, main.cpp:153-237, 1 spp per frame;\n"
         "                                           --out then names a printf pattern, one PPM per script line)");
@@ -25,7 +26,7 @@ static void usage() {
 
 int main(int argc, char** argv) {
     std::string scene = "cuda_default", integrator, out, raw, resume, script;
-    uint32_t W = 1280, H = 720, spp = 64, per = 0, depth = 0, seed = 0x5EED0001u, flags = 0;
+    uint32_t W = 1280, H = 720, spp = 64, per = 0, depth = 0, seed = 0x5EED0001u, flags = 0, flight = 1;
     int device = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -45,6 +46,7 @@ int main(int argc, char** argv) {
         else if (a == "--raw") raw = next();
         else if (a == "--resume") resume = next();
         else if (a == "--script") script = next();
+        else if (a == "--frames-in-flight") flight = (uint32_t)std::atoi(next());
         else { usage(); return a == "--help" ? 0 : 2; }
     }
     try {
@@ -61,6 +63,7 @@ int main(int argc, char** argv) {
         pt::Renderer r(device);
         r.setScene(s);
         r.setCamera(c);
+        if (flight > 1) r.setFramesInFlight(flight);
         const size_t npix = (size_t)W * H;
         uint32_t begin = 0;
         if (!resume.empty()) {  // raw (sum, count) checkpoint
