@@ -14,7 +14,9 @@
  * Threading: one context per GPU.  A context is not thread-safe; different
  * contexts may be driven from different threads.  All device work of a context
  * is enqueued on the context's stream (its own, or the one given to
- * pt_set_stream); nothing synchronises with the host unless documented.
+ * pt_set_stream); nothing synchronises with the host unless documented.  With
+ * pt_set_frames_in_flight(n > 1) path launches run on internal streams that fork
+ * from and join that stream (see there).
  */
 #ifndef PT_H_
 #define PT_H_
