@@ -640,10 +640,10 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
         const size_t waves = (size_t)blocks * 4u;
         if (ctx->trace_waves < waves) {
             if (ctx->trace) HIP_TRY(hipFree(ctx->trace));
-            HIP_TRY(hipMalloc((void**)&ctx->trace, waves * 64));
+            HIP_TRY(hipMalloc((void**)&ctx->trace, waves * 128));
             ctx->trace_waves = waves;
         }
-        HIP_TRY(hipMemsetAsync(ctx->trace, 0, waves * 64, stream));
+        HIP_TRY(hipMemsetAsync(ctx->trace, 0, waves * 128, stream));
         a.trace = ctx->trace;
     } else a.trace = nullptr;
     HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, blocks, stream));
@@ -652,7 +652,7 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
         ctx->burst++;
     }
     if (trace_file) {
-        std::vector<uint64_t> host((size_t)blocks * 4u * 8u);
+        std::vector<uint64_t> host((size_t)blocks * 4u * 16u);
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpy(host.data(), ctx->trace, host.size() * 8, hipMemcpyDeviceToHost));
         if (FILE* f = fopen(trace_file, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }

@@ -374,6 +374,11 @@ __global__ __launch_bounds__(256) PT_OCC void pt_path_kernel(const KArgs kargs) 
     // timeline of this wave (100 MHz constant clock): start, frame exhausted, first lane-parallel trip, end
     uint64_t tr_start = wall_clock64(), tr_exh = 0, tr_few = 0;
     uint32_t tr_trips = 0, tr_few_trips = 0, tr_few_rays = 0, tr_lane_trips = 0;
+    // shader-clock cycles this wave spent per section (s_memtime stamps; the stamps themselves cost ~10 %)
+    uint64_t tc_regen = 0, tc_isect = 0, tc_shade = 0, tc_mark = clock64();
+#define PT_SECTION(acc) { const uint64_t now_ = clock64(); acc += now_ - tc_mark; tc_mark = now_; }
+#else
+#define PT_SECTION(acc)
 #endif
 
     for (;;) {
@@ -504,6 +509,7 @@ __global__ __launch_bounds__(256) PT_OCC void pt_path_kernel(const KArgs kargs) 
             if (COUNT) c_samples++;
         }
         }  // regen
+        PT_SECTION(tc_regen)
         if (__ballot(alive) == 0ull) {
             // nothing in flight: done when no lane holds a pixel and the frame is exhausted;
             // otherwise some lane flushes / pulls on the next trip
@@ -522,6 +528,7 @@ __global__ __launch_bounds__(256) PT_OCC void pt_path_kernel(const KArgs kargs) 
         } else if (alive) {
             closest_hit<COUNT>(sc, o, d, t_hit, id_hit, c_roots);
         }
+        PT_SECTION(tc_isect)
         if (alive) {
             const float t = t_hit; const int id = id_hit;
             if (COUNT) { c_rays++; if (id >= 0) c_hits++; }
@@ -689,13 +696,15 @@ __global__ __launch_bounds__(256) PT_OCC void pt_path_kernel(const KArgs kargs) 
             }
             if (end_path) { sum = sum + L; alive = false; }
         }
+        PT_SECTION(tc_shade)
     }
 
 #ifdef PT_TRACE
     if (a.trace && lane == 0) {
-        uint64_t* tr = a.trace + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u;
+        uint64_t* tr = a.trace + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u;
         tr[0] = tr_start; tr[1] = tr_exh; tr[2] = tr_few; tr[3] = wall_clock64();
         tr[4] = tr_trips; tr[5] = tr_few_trips; tr[6] = tr_few_rays; tr[7] = tr_lane_trips;
+        tr[8] = tc_regen; tr[9] = tc_isect; tr[10] = tc_shade;
     }
 #endif
     if (COUNT && a.counters) {

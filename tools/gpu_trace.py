@@ -14,7 +14,7 @@ for name, (w, h), spp in (("cuda_default", (1280, 720), 1), ("cuda_default", (12
     r.set_scene(sc); r.set_camera(cam); r.reset()
     for i in range(3): r.render(i * spp, spp, abi.render_params(fused_rgba8=1))
     r.sync()
-    t = np.fromfile("/tmp/pt_trace.bin", dtype=np.uint64).reshape(-1, 8)
+    t = np.fromfile("/tmp/pt_trace.bin", dtype=np.uint64).reshape(-1, 16)
     t = t[t[:, 0] > 0]
     t0 = t[:, 0].min()
     us = lambda x: (x.astype(np.float64) - float(t0)) / 100.0   # 100 MHz
@@ -29,6 +29,9 @@ for name, (w, h), spp in (("cuda_default", (1280, 720), 1), ("cuda_default", (12
     print("   end - exhausted  ", q((end - exh)[t[:, 1] > 0]))
     print("   trips/wave       ", q(trips), " few-mode trips/wave", q(ftrips), " few rays/wave", q(frays))
     print(f"   lane utilisation of trips: {ltrips.sum() / (64 * trips.sum()):.3f};  few-mode share of trips {ftrips.sum() / trips.sum():.3f}")
+    cyc = t[:, 8:11].astype(np.float64).sum(axis=0)
+    print(f"   wave cycles by section: regeneration {cyc[0] / cyc.sum():.3f}, intersection {cyc[1] / cyc.sum():.3f}, shading {cyc[2] / cyc.sum():.3f}"
+          f"  ({cyc.sum() / trips.sum():.0f} cycles per wave-trip)")
     busy = end - start
     print(f"   mean trip time normal {((busy.sum()) / trips.sum()):.3f} us")
     late = np.argsort(end)[-5:]
