@@ -376,7 +376,9 @@ __global__ __launch_bounds__(256) PT_OCC void pt_path_kernel(const KArgs kargs) 
     uint32_t tr_trips = 0, tr_few_trips = 0, tr_few_rays = 0, tr_lane_trips = 0;
     // shader-clock cycles this wave spent per section (s_memtime stamps; the stamps themselves cost ~10 %)
     uint64_t tc_regen = 0, tc_isect = 0, tc_shade = 0, tc_mark = clock64();
-#define PT_SECTION(acc) { const uint64_t now_ = clock64(); acc += now_ - tc_mark; tc_mark = now_; }
+    uint64_t tf_regen = 0, tf_isect = 0, tf_shade = 0;  // the same, trips of the lane-parallel mode only
+    bool tr_in_few = false;
+#define PT_SECTION(acc) { const uint64_t now_ = clock64(); tc##acc += now_ - tc_mark; if (tr_in_few) tf##acc += now_ - tc_mark; tc_mark = now_; }
 #else
 #define PT_SECTION(acc)
 #endif
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(256) PT_OCC void pt_path_kernel(const KArgs kargs) 
             if (COUNT) c_samples++;
         }
         }  // regen
-        PT_SECTION(tc_regen)
+        PT_SECTION(_regen)
         if (__ballot(alive) == 0ull) {
             // nothing in flight: done when no lane holds a pixel and the frame is exhausted;
             // otherwise some lane flushes / pulls on the next trip
@@ -521,14 +523,15 @@ __global__ __launch_bounds__(256) PT_OCC void pt_path_kernel(const KArgs kargs) 
         const uint64_t alive_mask = __ballot(alive);
 #ifdef PT_TRACE
         tr_trips++; tr_lane_trips += (uint32_t)__popcll(alive_mask);
-        if ((uint32_t)__popcll(alive_mask) <= a.few_max) { if (!tr_few) tr_few = wall_clock64(); tr_few_trips++; tr_few_rays += (uint32_t)__popcll(alive_mask); }
+        tr_in_few = (uint32_t)__popcll(alive_mask) <= a.few_max;
+        if (tr_in_few) { if (!tr_few) tr_few = wall_clock64(); tr_few_trips++; tr_few_rays += (uint32_t)__popcll(alive_mask); }
 #endif
         if ((uint32_t)__popcll(alive_mask) <= a.few_max) {  // wave-uniform: all lanes take part
             closest_hit_few<COUNT>(sc, few_lds, alive_mask, (int)lane, o, d, t_hit, id_hit, c_roots);
         } else if (alive) {
             closest_hit<COUNT>(sc, o, d, t_hit, id_hit, c_roots);
         }
-        PT_SECTION(tc_isect)
+        PT_SECTION(_isect)
         if (alive) {
             const float t = t_hit; const int id = id_hit;
             if (COUNT) { c_rays++; if (id >= 0) c_hits++; }
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(256) PT_OCC void pt_path_kernel(const KArgs kargs) 
             }
             if (end_path) { sum = sum + L; alive = false; }
         }
-        PT_SECTION(tc_shade)
+        PT_SECTION(_shade)
     }
 
 #ifdef PT_TRACE
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(256) PT_OCC void pt_path_kernel(const KArgs kargs) 
         uint64_t* tr = a.trace + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u;
         tr[0] = tr_start; tr[1] = tr_exh; tr[2] = tr_few; tr[3] = wall_clock64();
         tr[4] = tr_trips; tr[5] = tr_few_trips; tr[6] = tr_few_rays; tr[7] = tr_lane_trips;
-        tr[8] = tc_regen; tr[9] = tc_isect; tr[10] = tc_shade;
+        tr[8] = tc_regen; tr[9] = tc_isect; tr[10] = tc_shade; tr[11] = tf_regen; tr[12] = tf_isect; tr[13] = tf_shade;
     }
 #endif
     if (COUNT && a.counters) {

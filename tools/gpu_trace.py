@@ -32,6 +32,10 @@ for name, (w, h), spp in (("cuda_default", (1280, 720), 1), ("cuda_default", (12
     cyc = t[:, 8:11].astype(np.float64).sum(axis=0)
     print(f"   wave cycles by section: regeneration {cyc[0] / cyc.sum():.3f}, intersection {cyc[1] / cyc.sum():.3f}, shading {cyc[2] / cyc.sum():.3f}"
           f"  ({cyc.sum() / trips.sum():.0f} cycles per wave-trip)")
+    fc = t[:, 11:14].astype(np.float64).sum(axis=0)
+    if ftrips.sum() > 0:
+        print(f"   lane-parallel trips: {fc.sum() / ftrips.sum():.0f} cycles per trip = regeneration {fc[0] / ftrips.sum():.0f} + intersection {fc[1] / ftrips.sum():.0f}"
+              f" + shading {fc[2] / ftrips.sum():.0f}; {frays.sum() / ftrips.sum():.2f} rays per trip  (a regeneration stamp of trip k+1 is booked to trip k's mode)")
     busy = end - start
     print(f"   mean trip time normal {((busy.sum()) / trips.sum()):.3f} us")
     late = np.argsort(end)[-5:]
