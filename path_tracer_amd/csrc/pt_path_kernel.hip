@@ -327,11 +327,14 @@ __device__ __forceinline__ const PT_CONST KArgs* cold() {
     return k;
 }
 
-#ifdef PT_WAVES_PER_EU  // occupancy experiments (make variant KFLAGS=-DPT_WAVES_PER_EU=7)
-#define PT_OCC __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU, PT_WAVES_PER_EU)))
-#else
-#define PT_OCC
+// Register budget.  The light-sampling build needs 102 VGPRs when left alone (4 waves/SIMD); asked for 5
+// waves/SIMD it fits 96 with two spilled registers and runs 8 % faster.  The plain build sits at 77 VGPRs
+// (6 waves/SIMD) and is left unconstrained: forcing 7 or 8 waves/SIMD spills and costs 6-27 %.
+#ifndef PT_NEE_WAVES
+#define PT_NEE_WAVES 5
 #endif
+#define PT_WAVES_PER_EU ((NEE && !COUNT) ? PT_NEE_WAVES : 1)
+#define PT_OCC __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU)))
 
 template <bool NEE, bool COUNT>
 __global__ __launch_bounds__(256) PT_OCC void pt_path_kernel(const KArgs kargs) {
