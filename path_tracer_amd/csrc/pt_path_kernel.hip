@@ -334,10 +334,14 @@ __device__ __forceinline__ const PT_CONST KArgs* cold() {
 #define PT_NEE_WAVES 5
 #endif
 #define PT_WAVES_PER_EU ((NEE && !COUNT) ? PT_NEE_WAVES : 1)
+// Threads per workgroup of the path kernel.  The host sizes grids in 256-thread units; the launcher converts.
+#ifndef PT_BLOCK
+#define PT_BLOCK 256
+#endif
 #define PT_OCC __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU)))
 
 template <bool NEE, bool COUNT>
-__global__ __launch_bounds__(256) PT_OCC void pt_path_kernel(const KArgs kargs) {
+__global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs kargs) {
     const DevSceneF& sc = kargs.sc;
     const PathArgs& a = kargs.a;
     const uint32_t lane = threadIdx.x & 63u;
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(256) PT_OCC void pt_path_kernel(const KArgs kargs) 
 
 #ifdef PT_TRACE
     if (a.trace && lane == 0) {
-        uint64_t* tr = a.trace + (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u;
+        uint64_t* tr = a.trace + (size_t)(blockIdx.x * (PT_BLOCK / 64u) + (threadIdx.x >> 6)) * 16u;
         tr[0] = tr_start; tr[1] = tr_exh; tr[2] = tr_few; tr[3] = wall_clock64();
         tr[4] = tr_trips; tr[5] = tr_few_trips; tr[6] = tr_few_rays; tr[7] = tr_lane_trips;
         tr[8] = tc_regen; tr[9] = tc_isect; tr[10] = tc_shade; tr[11] = tf_regen; tr[12] = tf_isect; tr[13] = tf_shade;
@@ -813,7 +817,7 @@ __global__ __launch_bounds__(256) void pt_valu_peak_kernel(float* sink, uint32_t
 
 hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArgs& a, bool nee, bool count,
                           uint32_t blocks, hipStream_t stream) {
-    const dim3 grid(blocks), block(256);
+    const dim3 grid((blocks * 256u + PT_BLOCK - 1u) / PT_BLOCK), block(PT_BLOCK);
     KArgs k;
     k.sc = sc; k.cam = cam; k.a = a;
     k.a.width = cam.width; k.a.height = cam.height;
@@ -830,16 +834,16 @@ hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArg
 hipError_t pt_path_resident_blocks(bool nee, bool count, int device, uint32_t* blocks) {
     int per_cu = 0;
     hipError_t e;
-    if (nee) e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<true, true>, 256, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<true, false>, 256, 0);
-    else e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<false, true>, 256, 0)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<false, false>, 256, 0);
+    if (nee) e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<true, true>, PT_BLOCK, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<true, false>, PT_BLOCK, 0);
+    else e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<false, true>, PT_BLOCK, 0)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<false, false>, PT_BLOCK, 0);
     if (e != hipSuccess) return e;
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
-    *blocks = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+    *blocks = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount * PT_BLOCK / 256u;
     return hipSuccess;
 }
 
