@@ -191,7 +191,9 @@ uint32_t pt_abi_version(void);
 /* Use an existing HIP stream (e.g. torch's current stream) for all work of the
  * context.  NULL is HIP's null (legacy default) stream, which is what torch's
  * default stream is.  pt_use_own_stream() goes back to the context's own
- * non-blocking stream. */
+ * non-blocking stream.  Work the context already queued on the stream it
+ * leaves stays ordered before whatever is queued on the new one (an event wait,
+ * no host synchronisation). */
 int pt_set_stream(PtContext* ctx, void* hip_stream);
 int pt_use_own_stream(PtContext* ctx);
 

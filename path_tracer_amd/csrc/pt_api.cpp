@@ -141,6 +141,18 @@ int join_chains(PtContext* ctx) {
     return PT_OK;
 }
 
+// Work already queued on the old stream (frame clears, launches, resolves) stays ordered before
+// whatever the caller queues on the new one.
+int switch_stream(PtContext* ctx, hipStream_t to) {
+    if (int rc = join_chains(ctx)) return rc;
+    if (to == ctx->stream) return PT_OK;
+    if (!ctx->fork_event) HIP_TRY(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ctx->fork_event, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(to, ctx->fork_event, 0));
+    ctx->stream = to;
+    return PT_OK;
+}
+
 // Streams, events and accumulators of chains 1..flight-1 for the current frame size (zeroed).
 int prepare_chains(PtContext* ctx) {
     const size_t npix = (size_t)ctx->width * ctx->height;
@@ -252,16 +264,12 @@ int pt_destroy(PtContext* ctx) {
 
 int pt_set_stream(PtContext* ctx, void* hip_stream) {
     if (int rc = use(ctx)) return rc;
-    if (int rc = join_chains(ctx)) return rc;
-    ctx->stream = (hipStream_t)hip_stream;
-    return PT_OK;
+    return switch_stream(ctx, (hipStream_t)hip_stream);
 }
 
 int pt_use_own_stream(PtContext* ctx) {
     if (int rc = use(ctx)) return rc;
-    if (int rc = join_chains(ctx)) return rc;
-    ctx->stream = ctx->own_stream;
-    return PT_OK;
+    return switch_stream(ctx, ctx->own_stream);
 }
 
 int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
@@ -797,18 +805,19 @@ int pt_valu_peak(PtContext* ctx, uint32_t packed, uint32_t iters, double* out_tf
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
     const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 8u;  // 8 blocks x 4 waves = 8 waves / SIMD
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(pt_launch_valu_peak(ctx->sink, packed, iters, blocks, ctx->stream));  // warm-up
-    HIP_TRY(hipEventRecord(e0, ctx->stream));
-    HIP_TRY(pt_launch_valu_peak(ctx->sink, packed, iters, blocks, ctx->stream));
-    HIP_TRY(hipEventRecord(e1, ctx->stream));
-    HIP_TRY(hipEventSynchronize(e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = pt_launch_valu_peak(ctx->sink, packed, iters, blocks, ctx->stream);  // warm-up
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+    if (e == hipSuccess) e = pt_launch_valu_peak(ctx->sink, packed, iters, blocks, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return fail(PT_ERR_HIP, "ceiling micro-benchmark failed: %s", hipGetErrorString(e));
     const double flops = (double)blocks * 256.0 * (double)iters * 16.0 * 2.0;
     *out_tflops = flops / ((double)ms * 1e-3) / 1e12;
     return PT_OK;

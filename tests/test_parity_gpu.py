@@ -367,6 +367,39 @@ def test_bound_torch_tensor_is_the_accumulation_buffer(gpu):
     assert np.all(gpu.accum()[..., 3] == 4)  # back on the context's own buffer
 
 
+def test_stream_switch_keeps_queued_work_ordered(gpu):
+    """pt_set_stream / pt_use_own_stream with work still queued: the frame clear and the launches
+    queued on the old stream stay ordered before the launches queued on the new one."""
+    import torch
+    sc, cam = scenes.cuda_default(640, 360)
+    _setup(gpu, sc, cam)
+    for s in range(6):
+        gpu.render(s, 1, abi.render_params())
+    want = gpu.accum()
+    side = torch.cuda.Stream()
+    for flight in (1, 3):
+        gpu.set_frames_in_flight(flight)
+        gpu.use_own_stream()
+        gpu.set_camera(scenes.cuda_default(64, 36)[1])  # reallocates: the clear below is queued, not waited for
+        gpu.set_camera(cam)
+        gpu.render(0, 1, abi.render_params())
+        gpu.render(1, 1, abi.render_params())
+        with torch.cuda.stream(side):
+            gpu.use_torch_stream()
+            gpu.render(2, 1, abi.render_params())
+            gpu.render(3, 1, abi.render_params())
+        gpu.use_own_stream()
+        gpu.render(4, 1, abi.render_params())
+        gpu.render(5, 1, abi.render_params())
+        got = gpu.accum()
+        assert np.array_equal(got[..., 3], want[..., 3])
+        if flight == 1:
+            assert np.array_equal(got, want)
+        else:
+            assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=1e-6)
+    gpu.set_frames_in_flight(1)
+
+
 # ------------------------------------------------------------------ frames in flight ---
 @pytest.mark.parametrize("n", [2, 3, 4])
 def test_frames_in_flight_match_serial(gpu, n):
