@@ -234,7 +234,12 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
  * which is asynchronous on the context's stream.  The image is reproducible
  * run to run; it differs from the n = 1 image only by float summation order.
  * A fused display (fused_rgba8) written while other launches are in flight
- * shows, per pixel, a mean that may or may not include their newest sample. */
+ * shows, per pixel, a mean that may or may not include their newest sample.
+ * With n > 1 a pt_render call for more than 48 samples per pixel on a frame of
+ * at most 2^22 pixels is itself dealt to the chains as launches of about 32
+ * samples (a pixel belongs to one lane per launch, so one long launch over few
+ * pixels per lane ends with most lanes idle): throughput then does not depend
+ * on how the caller slices the samples. */
 int pt_set_frames_in_flight(PtContext* ctx, uint32_t n);
 int pt_flush(PtContext* ctx);
 /* Resolve the accumulation buffer into the context's display buffer

@@ -86,8 +86,8 @@ struct PtContext {
     size_t trace_waves = 0;
     uint32_t resident_blocks[4] = {0, 0, 0, 0};  // per kernel variant (nee, count)
     // tuning / tracing knobs for tools/gpu_ab.py and tools/gpu_trace.py, read once at pt_create
-    // (PT_AMD_FEW_MAX, PT_AMD_MAX_BLOCKS, PT_AMD_TRACE); -1 / empty = not set
-    int knob_few_max = -1, knob_max_blocks = -1;
+    // (PT_AMD_FEW_MAX, PT_AMD_MAX_BLOCKS, PT_AMD_CHUNK, PT_AMD_TRACE); -1 / empty = not set
+    int knob_few_max = -1, knob_max_blocks = -1, knob_chunk = -1;
     std::string knob_trace;
 };
 
@@ -225,6 +225,7 @@ int pt_create(int device_id, PtContext** out) {
     if (const char* e = getenv("PT_AMD_FEW_MAX")) ctx->knob_few_max = atoi(e);
     if (const char* e = getenv("PT_AMD_MAX_BLOCKS")) ctx->knob_max_blocks = atoi(e);
     if (const char* e = getenv("PT_AMD_TRACE")) ctx->knob_trace = e;
+    if (const char* e = getenv("PT_AMD_CHUNK")) ctx->knob_chunk = atoi(e);
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(PT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     ctx->stream = ctx->own_stream;
@@ -576,6 +577,22 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     // frames in flight: sums only (a running mean is a recurrence on one buffer), and not while
     // a per-launch trace is being written
     const bool pipelined = ctx->flight > 1 && prm->acc_mode == PT_ACC_SUM && ctx->knob_trace.empty();
+    // A pixel belongs to one lane for the whole launch, so a launch with many samples per pixel and few
+    // pixels per lane (2.3 at 720p) ends with most lanes idle while the last pixels finish: one 256-sample
+    // launch at 720p runs at 6.1 Gsamples/s, the same samples in 32-sample launches dealt to three chains
+    // at 10.2.  With frames in flight the call is therefore cut into such launches here.  (4K launches
+    // hold 21 pixels per lane and are left whole.)
+    const uint32_t chunk = ctx->knob_chunk >= 0 ? (uint32_t)ctx->knob_chunk : 32u;
+    if (pipelined && chunk > 0 && sample_count > chunk + chunk / 2u && (uint64_t)ctx->width * ctx->height <= (1ull << 22)) {
+        const uint32_t parts = (sample_count + chunk - 1u) / chunk;
+        uint32_t begin = sample_begin, left = sample_count;
+        for (uint32_t k = 0; k < parts; ++k) {
+            const uint32_t n = (left + (parts - k) - 1u) / (parts - k);  // as equal as integers allow
+            if (int rc = pt_render(ctx, begin, n, prm)) return rc;
+            begin += n; left -= n;
+        }
+        return PT_OK;
+    }
     uint32_t chain = 0;
     hipStream_t stream = ctx->stream;
     if (pipelined) {

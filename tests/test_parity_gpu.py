@@ -444,6 +444,35 @@ def test_frames_in_flight_match_serial(gpu, n):
         gpu.set_frames_in_flight(1)
 
 
+def test_frames_in_flight_cut_large_calls_into_launches(gpu):
+    """With frames in flight one call for many samples per pixel is dealt to the chains in launches of
+    ~32 samples (pt_api.cpp, pt_render): same samples, each once, whatever the call size."""
+    sc, cam = scenes.cuda_default(320, 180)
+    _setup(gpu, sc, cam)
+    gpu.render(7, 150, abi.render_params())
+    serial = gpu.accum()
+    gpu.set_frames_in_flight(3)
+    try:
+        runs = []
+        for rep in range(2):
+            _setup(gpu, sc, cam)
+            gpu.render(7, 150, abi.render_params())
+            runs.append(gpu.accum())
+        assert np.array_equal(runs[0], runs[1])
+        assert np.all(runs[0][..., 3] == 150)
+        np.testing.assert_allclose(runs[0][..., :3], serial[..., :3], rtol=1e-5, atol=1e-5)
+        # the same samples asked for in three calls of unequal size
+        _setup(gpu, sc, cam)
+        gpu.render(7, 49, abi.render_params())
+        gpu.render(56, 100, abi.render_params())
+        gpu.render(156, 1, abi.render_params())
+        got = gpu.accum()
+        assert np.all(got[..., 3] == 150)
+        np.testing.assert_allclose(got[..., :3], serial[..., :3], rtol=1e-5, atol=1e-5)
+    finally:
+        gpu.set_frames_in_flight(1)
+
+
 def test_frames_in_flight_random_call_sequences(gpu):
     """Any interleaving of renders with the calls that read, replace or re-target the accumulation buffer keeps
     the books: the buffer always holds exactly the samples rendered since the last reset, each once."""
