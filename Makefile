@@ -56,8 +56,9 @@ clean:
 
 .PHONY: all oracle clean isa
 
-# kernel-variant build for A/B runs:  make variant NAME=v1 KFLAGS="-fno-slp-vectorize"
+# kernel-variant build for A/B runs:  make variant NAME=v1 VFLAGS="-DPT_BLOCK=128"
+# (VFLAGS are added to KFLAGS; overriding KFLAGS itself drops -fno-slp-vectorize and costs ~13 %)
 variant: build/pt_api.o build/pt_f64_kernels.o build/pt_builtin_scenes.o build/pt_fly_camera.o
 	@mkdir -p build/var_$(NAME)
-	$(HIPCC) $(HIPFLAGS) $(KFLAGS) -c $(CSRC)/pt_path_kernel.hip -o build/var_$(NAME)/pt_path_kernel.o
+	$(HIPCC) $(HIPFLAGS) $(KFLAGS) $(VFLAGS) -c $(CSRC)/pt_path_kernel.hip -o build/var_$(NAME)/pt_path_kernel.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libpt_amd_$(NAME).so build/pt_api.o build/var_$(NAME)/pt_path_kernel.o build/pt_f64_kernels.o build/pt_builtin_scenes.o build/pt_fly_camera.o

@@ -49,7 +49,7 @@ def main() -> int:
     ap.add_argument("--workload", default="cornell_720p_progressive_1spp", choices=sorted(WORKLOADS))
     ap.add_argument("--mis", action="store_true", help="next-event estimation + MIS (north_star variant)")
     ap.add_argument("--pixels-per-wave", type=int, default=0)
-    ap.add_argument("--frames-in-flight", type=int, default=3, choices=(1, 2, 3, 4),
+    ap.add_argument("--frames-in-flight", type=int, default=4, choices=(1, 2, 3, 4),
                     help="consecutive launches overlapped on internal streams (include/pt.h); 1 = strictly serial launches")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
     args = ap.parse_args()

@@ -1,4 +1,4 @@
-"""Per-wave timeline of one launch (needs a PT_TRACE kernel build: make variant NAME=trace KFLAGS="-fno-slp-vectorize -DPT_TRACE").
+"""Per-wave timeline of one launch (needs a PT_TRACE kernel build: make variant NAME=trace VFLAGS="-DPT_TRACE").
 python tools/gpu_trace.py [few_max]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
