@@ -235,11 +235,20 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
  * run to run; it differs from the n = 1 image only by float summation order.
  * A fused display (fused_rgba8) written while other launches are in flight
  * shows, per pixel, a mean that may or may not include their newest sample.
- * With n > 1 a pt_render call for more than 48 samples per pixel on a frame of
- * at most 2^22 pixels is itself dealt to the chains as launches of about 32
- * samples (a pixel belongs to one lane per launch, so one long launch over few
- * pixels per lane ends with most lanes idle): throughput then does not depend
- * on how the caller slices the samples. */
+ * n = 4 needs more hardware queues than HIP's default of 4 per process
+ * (GPU_MAX_HW_QUEUES=8 in the environment before HIP initialises); with the
+ * default two chains share a queue and n = 4 is slower than n = 3.
+ *
+ * Large calls.  A pixel belongs to one lane per launch, so one long launch over
+ * few pixels per lane (2.3 at 1280x720) ends with most lanes idle.  On frames
+ * of at most 2^22 pixels a PT_ACC_SUM path call is therefore executed as several
+ * launches of 8..32 samples on the internal streams: with n > 1, calls for more
+ * than 48 samples join the open burst; with n = 1, a call for 12 samples or
+ * more is a burst of its own on three chains, folded (and, with fused_rgba8,
+ * resolved) before pt_render returns, so nothing stays in flight.  The partition
+ * depends only on the call's arguments: the image is reproducible and equals
+ * the single launch's up to float summation order.  (Environment variable
+ * PT_AMD_CHUNK=0, read at pt_create, keeps every call one launch.) */
 int pt_set_frames_in_flight(PtContext* ctx, uint32_t n);
 int pt_flush(PtContext* ctx);
 /* Resolve the accumulation buffer into the context's display buffer

@@ -473,6 +473,36 @@ def test_frames_in_flight_cut_large_calls_into_launches(gpu):
         gpu.set_frames_in_flight(1)
 
 
+def test_large_serial_calls_are_split_over_the_chains(gpu, monkeypatch):
+    """Without frames in flight a call for >= 12 samples per pixel is a burst of its own on three chains,
+    folded before the call returns: the same samples as the single launch (PT_AMD_CHUNK=0), reproducible,
+    and a fused display that equals the resolve pass."""
+    from path_tracer_amd.renderer import Renderer
+    sc, cam = scenes.cuda_default(320, 180)
+    monkeypatch.setenv("PT_AMD_CHUNK", "0")
+    whole = Renderer(0)
+    monkeypatch.delenv("PT_AMD_CHUNK")
+    try:
+        _setup(whole, sc, cam)
+        whole.render(3, 40, abi.render_params())
+        want = whole.accum()
+    finally:
+        whole.close()
+    runs = []
+    for rep in range(2):
+        _setup(gpu, sc, cam)
+        gpu.render(3, 40, abi.render_params(fused_rgba8=1))
+        fused = gpu.readback(abi.RESOLVE_RGBA8_CUDA)
+        runs.append(gpu.accum())
+        assert np.array_equal(fused, gpu.resolve_to_host(abi.RESOLVE_RGBA8_CUDA))
+    assert np.array_equal(runs[0], runs[1])
+    assert np.all(runs[0][..., 3] == 40)
+    np.testing.assert_allclose(runs[0][..., :3], want[..., :3], rtol=1e-5, atol=1e-5)
+    # and the next call continues on the same buffer
+    gpu.render(43, 5, abi.render_params())
+    assert np.all(gpu.accum()[..., 3] == 45)
+
+
 def test_frames_in_flight_random_call_sequences(gpu):
     """Any interleaving of renders with the calls that read, replace or re-target the accumulation buffer keeps
     the books: the buffer always holds exactly the samples rendered since the last reset, each once."""

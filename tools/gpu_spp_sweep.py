@@ -2,7 +2,7 @@
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if len(sys.argv) > 1: os.environ["GPU_MAX_HW_QUEUES"] = sys.argv[1]
 from path_tracer_amd import abi, scenes
 from path_tracer_amd.renderer import Renderer
 r = Renderer(0)
@@ -10,9 +10,9 @@ out = {}
 for name, (w, h) in {"720p": (1280, 720), "1080p": (1920, 1080), "360p": (640, 360)}.items():
     sc, cam = scenes.cuda_default(w, h)
     r.set_scene(sc); r.set_camera(cam)
-    for flight in (3,):
+    for flight in (1,):
         r.set_frames_in_flight(flight)
-        for spl in (16, 64, 256, 1024):
+        for spl in (16, 32, 64, 128, 256, 512, 2048):
             total = 1024 if name != "4k" else 256
             launches = max(1, total // spl)
             r.reset(); r.render(0, spl, abi.render_params()); r.sync()
