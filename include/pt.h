@@ -233,8 +233,9 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
  * reads pt_accum_device_ptr() or a bound buffer itself calls pt_flush() first,
  * which is asynchronous on the context's stream.  The image is reproducible
  * run to run; it differs from the n = 1 image only by float summation order.
- * A fused display (fused_rgba8) written while other launches are in flight
- * shows, per pixel, a mean that may or may not include their newest sample.
+ * A fused display (fused_rgba8) is then made by a pass of its own behind each
+ * launch; written while other launches are in flight it shows, per pixel, a
+ * mean that may or may not include their newest sample.
  * n = 4 needs more hardware queues than HIP's default of 4 per process
  * (GPU_MAX_HW_QUEUES=8 in the environment before HIP initialises); with the
  * default two chains share a queue and n = 4 is slower than n = 3.

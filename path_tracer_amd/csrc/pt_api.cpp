@@ -631,12 +631,9 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     }
     PathArgs a{};
     a.accum = chain == 0 ? ctx->accum : ctx->chain_acc[chain];
-    if (pipelined && prm->fused_rgba8) {
-        uint32_t k = 0;
-        for (uint32_t c = 0; c < ctx->flight; ++c)
-            if (c != chain) a.other[k++] = c == 0 ? ctx->accum : ctx->chain_acc[c];
-    }
-    a.rgba = prm->fused_rgba8 ? (uint32_t*)ctx->display : nullptr;
+    // a launch that overlaps others displays in a pass of its own behind it (pt_display_kernel): the mean over all chains
+    const bool display_pass = pipelined && prm->fused_rgba8;
+    a.rgba = (prm->fused_rgba8 && !display_pass) ? (uint32_t*)ctx->display : nullptr;
     a.counters = (prm->flags & PT_FLAG_COUNTERS) ? ctx->counters : nullptr;
     a.s0 = sample_begin; a.count = sample_count;
     a.max_depth = prm->max_depth; a.rr_depth = prm->rr_depth; a.seed_hash = hash32(prm->seed);
@@ -650,25 +647,26 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     if (resident == 0) HIP_TRY(pt_path_resident_blocks(nee, cnt, ctx->device, &resident));
     a.inv_tiles_x = 1.0f / (float)a.tiles_x;
     a.total_w = (float)(sample_begin + sample_count); a.inv_total_w = 1.0f / a.total_w;
+    // Grid: no more waves than are resident at once.  Overlapping launches fill the chip together, so each
+    // can be smaller: fewer waves means more pixels per lane (lanes that regenerate instead of idling until
+    // the launch ends).  Aim at >= 7 pixels per lane, but keep the chains' grids together ~1.35x the
+    // resident capacity.  (measured at 720p, 1 spp: 3 x 1536 blocks 6.3, 3 x 768 6.7, 4 x 512 6.9 Gsamples/s)
+    uint32_t cap = resident;
+    if (pipelined) {
+        const uint32_t by_work = (uint32_t)(((uint64_t)ctx->width * ctx->height) / (256u * 7u));
+        const uint32_t by_fill = (resident * 27u) / (20u * ctx->flight);
+        const uint32_t want = by_work > by_fill ? by_work : by_fill;
+        if (want < cap) cap = want;
+    }
     // work unit = 4x4 pixels; a ticket is at least units_per_grab of them.  Default: aim at >= 8
-    // tickets per resident wave, but never more than one 8x8 tile per ticket.
+    // tickets per wave of the grid, but never more than one 8x8 tile per ticket.
     const uint32_t units = a.num_tiles * 4u;
     uint32_t upg;
     if (prm->pixels_per_wave) upg = (prm->pixels_per_wave + 15u) / 16u;
-    else { upg = units / (resident * 4u * 8u); upg = upg > 4u ? 4u : upg; }
+    else { upg = units / (cap * 4u * 8u); upg = upg > 4u ? 4u : upg; }
     a.units_per_grab = upg < 1u ? 1u : (upg > 65536u ? 65536u : upg);
     uint32_t blocks = (units / a.units_per_grab + 3u) / 4u;  // no more waves than tickets ...
-    if (blocks > resident) blocks = resident;                // ... and no more than are resident at once
-    if (pipelined) {
-        // Overlapping launches fill the chip together, so each can be smaller: fewer waves means more
-        // pixels per lane (lanes that regenerate instead of idling until the launch ends).  Aim at
-        // >= 7 pixels per lane, but keep the chains' grids together ~1.35x the resident capacity.
-        // (measured at 720p, 1 spp: 3 x 1536 blocks 6.3, 3 x 768 6.7, 4 x 512 6.9 Gsamples/s)
-        const uint32_t by_work = (uint32_t)(((uint64_t)ctx->width * ctx->height) / (256u * 7u));
-        const uint32_t by_fill = (resident * 27u) / (20u * ctx->flight);
-        uint32_t want = by_work > by_fill ? by_work : by_fill;
-        if (want < blocks) blocks = want;
-    }
+    if (blocks > cap) blocks = cap;                          // ... and no more than the cap
     {   // lane-parallel intersection pays while (rays in flight) x (per-ray cost) < cost of one 64-ray pass
         const DevSceneF& f = ctx->sf;
         const uint32_t serial = 25u * (uint32_t)f.ns + 7u * (uint32_t)(f.nax + f.nay + f.naz) + 13u * (uint32_t)f.npg + 35u * (uint32_t)f.nt;
@@ -695,6 +693,10 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
         a.trace = ctx->trace;
     } else a.trace = nullptr;
     HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, blocks, stream));
+    if (display_pass)
+        HIP_TRY(pt_launch_display(ctx->accum, ctx->chain_acc[1], ctx->flight > 2 ? ctx->chain_acc[2] : nullptr,
+                                  ctx->flight > 3 ? ctx->chain_acc[3] : nullptr, (uint32_t*)ctx->display,
+                                  ctx->width * ctx->height, stream));
     if (pipelined) {
         HIP_TRY(hipEventRecord(ctx->chain_done[chain], stream));
         ctx->burst++;

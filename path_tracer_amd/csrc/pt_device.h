@@ -47,7 +47,6 @@ struct DevCamF {
 struct PathArgs {
     float4* accum;
     uint32_t* rgba;          // display buffer (fused resolve) or nullptr
-    const float4* other[3];  // frames in flight: the other chains' accumulators (display only), nullptr-terminated
     uint64_t* counters;      // 12 x u64 (PtCounters order) or nullptr
     uint32_t* work_counter;  // this launch's 8 ticket counters on separate 128-B lines (word 32*s), zero at start
     uint32_t* next_counter;  // the chain's other set: zeroed by this launch for the chain's next one
@@ -97,6 +96,8 @@ hipError_t pt_path_resident_blocks(bool nee, bool count, int device, uint32_t* b
 hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint32_t acc_mode, uint32_t mode,
                              hipStream_t stream);
 hipError_t pt_launch_merge(float4* acc0, float4* c1, float4* c2, float4* c3, uint32_t npix, hipStream_t stream);
+hipError_t pt_launch_display(const float4* c0, const float4* c1, const float4* c2, const float4* c3, uint32_t* rgba,
+                             uint32_t npix, hipStream_t stream);
 hipError_t pt_launch_valu_peak(float* sink, uint32_t packed, uint32_t iters, uint32_t blocks, hipStream_t stream);
 hipError_t pt_launch_primary_ids(const DevSceneD& sc, const DevCamD& cam, uint32_t* obj, uint32_t* mat,
                                  hipStream_t stream);

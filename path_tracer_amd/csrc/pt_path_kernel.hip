@@ -421,26 +421,10 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
             }
             a.accum[pixel] = acc;
             uint32_t* const rgba = kc->a.rgba;
-            if (rgba) {  // fused convertToRGBAKernel
-                if (kc->a.other[0]) {
-                    // frames in flight: the displayed mean also counts the samples the other chains hold
-                    // for this pixel.  Their launches may be running, so this reads each (sum, n) either
-                    // before or after their 16-B store: a consistent mean either way, display only.
-                    float4 tot = acc;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float4* const other = kc->a.other[k];
-                        if (!other) break;
-                        const float4 q = other[pixel];
-                        tot.x += q.x; tot.y += q.y; tot.z += q.z; tot.w += q.w;
-                    }
-                    const float inv = rcp(tot.w);
-                    rgba[pixel] = pack_rgba8_cuda(tot.x * inv, tot.y * inv, tot.z * inv);
-                } else {
-                    // every pixel normally holds the same count: its reciprocal comes from the host (same IEEE divide)
-                    const float inv = (a.acc_mode != 0u) ? 1.0f : (acc.w == kc->a.total_w ? kc->a.inv_total_w : 1.0f / acc.w);
-                    rgba[pixel] = pack_rgba8_cuda(acc.x * inv, acc.y * inv, acc.z * inv);
-                }
+            if (rgba) {  // fused convertToRGBAKernel (launches that overlap others display in a pass of their own)
+                // every pixel normally holds the same count: its reciprocal comes from the host (same IEEE divide)
+                const float inv = (a.acc_mode != 0u) ? 1.0f : (acc.w == kc->a.total_w ? kc->a.inv_total_w : 1.0f / acc.w);
+                rgba[pixel] = pack_rgba8_cuda(acc.x * inv, acc.y * inv, acc.z * inv);
             }
             my = -1;
         }
@@ -780,6 +764,24 @@ __global__ __launch_bounds__(256) void pt_merge_kernel(float4* __restrict__ acc0
     acc0[p] = a;
 }
 
+// Frames in flight: the display of a frame, as a pass of its own behind the frame's launch on the chain's
+// stream.  It shows the mean over all chains (their launches may be running: each (sum, n) is read either
+// before or after its 16-B store, a consistent mean either way; display only).  The path launches are VALU-
+// bound and leave HBM idle, so these 68 B per pixel ride along; fused into the path kernel the same reads
+// sit in the regeneration block at low lane occupancy and cost 7 % of the frame rate.
+__global__ __launch_bounds__(256) void pt_display_kernel(const float4* __restrict__ c0, const float4* __restrict__ c1,
+                                                         const float4* __restrict__ c2, const float4* __restrict__ c3,
+                                                         uint32_t* __restrict__ rgba, uint32_t npix) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= npix) return;
+    float4 a = c0[p];
+    if (c1) { const float4 q = c1[p]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
+    if (c2) { const float4 q = c2[p]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
+    if (c3) { const float4 q = c3[p]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
+    const float inv = a.w > 0.0f ? 1.0f / a.w : 0.0f;
+    rgba[p] = pack_rgba8_cuda(a.x * inv, a.y * inv, a.z * inv);
+}
+
 // ------------------------------------------------------------------------------------------
 // FP32 VALU ceiling: 16 independent FMA chains per lane, `iters` rounds.  packed != 0 runs the
 // chains as float2 so hipcc emits v_pk_fma_f32.  FLOPs = lanes * iters * 16 * 2.
@@ -859,6 +861,12 @@ hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint
 
 hipError_t pt_launch_merge(float4* acc0, float4* c1, float4* c2, float4* c3, uint32_t npix, hipStream_t stream) {
     hipLaunchKernelGGL(pt_merge_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, acc0, c1, c2, c3, npix);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_display(const float4* c0, const float4* c1, const float4* c2, const float4* c3, uint32_t* rgba,
+                             uint32_t npix, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_display_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, c0, c1, c2, c3, rgba, npix);
     return hipGetLastError();
 }
 
