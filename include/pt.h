@@ -221,7 +221,7 @@ int pt_reset(PtContext* ctx);
  * Asynchronous on the context's stream. */
 int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
               const PtRenderParams* params);
-/* Frames in flight (1..4, default 1).  With n > 1, consecutive PT_ACC_SUM path
+/* Frames in flight (1..8, default 1).  With n > 1, consecutive PT_ACC_SUM path
  * launches go round-robin to n internal streams, each with an accumulator of
  * its own, so launch k+1 fills the compute units that launch k leaves idle
  * while its last long paths finish (the reference's frame loop,
@@ -236,9 +236,10 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
  * A fused display (fused_rgba8) is then made by a pass of its own behind each
  * launch; written while other launches are in flight it shows, per pixel, a
  * mean that may or may not include their newest sample.
- * n = 4 needs more hardware queues than HIP's default of 4 per process
- * (GPU_MAX_HW_QUEUES=8 in the environment before HIP initialises); with the
- * default two chains share a queue and n = 4 is slower than n = 3.
+ * n > 3 needs more hardware queues than HIP's default of 4 per process:
+ * GPU_MAX_HW_QUEUES >= n + 4 in the environment before HIP initialises (16 for
+ * n = 8).  Chains that share a queue serialise: with the default, n = 4 is
+ * slower than n = 3.  Memory: n - 1 more accumulation buffers.
  *
  * Large calls.  A pixel belongs to one lane per launch, so one long launch over
  * few pixels per lane (2.3 at 1280x720) ends with most lanes idle.  On frames

@@ -71,15 +71,15 @@ struct PtContext {
     uint64_t* counters = nullptr;  // 12 x u64
     uint32_t* ids = nullptr;       // 2 * npix, allocated on demand
     float* sink = nullptr;
-    uint32_t* work_counter = nullptr;  // ticket counters of the path kernel: 4 chains x 2 alternating sets x 8 shards x 128 B
-    uint32_t work_parity[4] = {0, 0, 0, 0};  // per chain: which of its two sets the next launch uses
+    uint32_t* work_counter = nullptr;  // ticket counters of the path kernel: 8 chains x 2 alternating sets x 8 shards x 128 B
+    uint32_t work_parity[PT_MAX_CHAINS] = {};  // per chain: which of its two sets the next launch uses
     // frames in flight (pt_set_frames_in_flight): launch k of a burst goes to chain k % flight, which
     // has its own stream and its own accumulator; chain 0's accumulator is the context's (or the bound one)
     uint32_t flight = 1;
-    hipStream_t chain_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t chain_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t chain_stream[PT_MAX_CHAINS] = {};
+    hipEvent_t chain_done[PT_MAX_CHAINS] = {};
     hipEvent_t fork_event = nullptr;
-    float4* chain_acc[4] = {nullptr, nullptr, nullptr, nullptr};  // [0] unused (= accum)
+    float4* chain_acc[PT_MAX_CHAINS] = {};  // [0] unused (= accum)
     size_t chain_acc_pixels = 0;
     uint32_t burst = 0;                // launches since the chains were last joined
     uint64_t* trace = nullptr;         // PT_AMD_TRACE=<file>: per-wave timeline of the last launch (PT_TRACE kernel builds)
@@ -125,6 +125,14 @@ int alloc_frame(PtContext* ctx, uint32_t w, uint32_t h) {
 
 constexpr size_t WORK_SET_WORDS = 256;  // 8 shards x 32 words (128 B apart)
 
+ChainAccs chain_accs(const PtContext* ctx, uint32_t n) {
+    ChainAccs c{};
+    c.acc[0] = ctx->accum;
+    for (uint32_t k = 1; k < n; ++k) c.acc[k] = ctx->chain_acc[k];
+    c.n = n;
+    return c;
+}
+
 // Frames in flight: makes the context's stream wait for every chain and folds the chains'
 // accumulators into the context's.  A no-op when no burst is open.
 int join_chains(PtContext* ctx) {
@@ -132,10 +140,7 @@ int join_chains(PtContext* ctx) {
     const uint32_t used = ctx->burst < ctx->flight ? ctx->burst : ctx->flight;
     for (uint32_t c = 0; c < used; ++c) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->chain_done[c], 0));
     if (used > 1) {
-        float4* c1 = ctx->chain_acc[1];
-        float4* c2 = used > 2 ? ctx->chain_acc[2] : nullptr;
-        float4* c3 = used > 3 ? ctx->chain_acc[3] : nullptr;
-        HIP_TRY(pt_launch_merge(ctx->accum, c1, c2, c3, ctx->width * ctx->height, ctx->stream));
+        HIP_TRY(pt_launch_merge(chain_accs(ctx, used), ctx->width * ctx->height, ctx->stream));
     }
     ctx->burst = 0;
     return PT_OK;
@@ -165,7 +170,7 @@ int prepare_chains(PtContext* ctx) {
         if (!ctx->chain_done[c]) HIP_TRY(hipEventCreateWithFlags(&ctx->chain_done[c], hipEventDisableTiming));
     }
     if (ctx->chain_acc_pixels != npix) {
-        for (uint32_t c = 1; c < 4; ++c)
+        for (uint32_t c = 1; c < PT_MAX_CHAINS; ++c)
             if (ctx->chain_acc[c]) { HIP_TRY(hipFree(ctx->chain_acc[c])); ctx->chain_acc[c] = nullptr; }
         ctx->chain_acc_pixels = npix;
     }
@@ -232,8 +237,8 @@ int pt_create(int device_id, PtContext** out) {
     e = hipMalloc((void**)&ctx->counters, 12 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMemset(ctx->counters, 0, 12 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->sink, 256);
-    if (e == hipSuccess) e = hipMalloc((void**)&ctx->work_counter, 8 * WORK_SET_WORDS * 4);
-    if (e == hipSuccess) e = hipMemset(ctx->work_counter, 0, 8 * WORK_SET_WORDS * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->work_counter, 2 * PT_MAX_CHAINS * WORK_SET_WORDS * 4);
+    if (e == hipSuccess) e = hipMemset(ctx->work_counter, 0, 2 * PT_MAX_CHAINS * WORK_SET_WORDS * 4);
     if (e != hipSuccess) { pt_destroy(ctx); return fail(PT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e)); }
     *out = ctx;
     return PT_OK;
@@ -242,7 +247,7 @@ int pt_create(int device_id, PtContext** out) {
 int pt_destroy(PtContext* ctx) {
     if (!ctx) return PT_OK;
     (void)hipSetDevice(ctx->device);
-    for (int c = 0; c < 4; ++c) {
+    for (uint32_t c = 0; c < PT_MAX_CHAINS; ++c) {
         if (c > 0 && ctx->chain_stream[c]) { (void)hipStreamSynchronize(ctx->chain_stream[c]); (void)hipStreamDestroy(ctx->chain_stream[c]); }
         if (ctx->chain_done[c]) (void)hipEventDestroy(ctx->chain_done[c]);
         if (ctx->chain_acc[c]) (void)hipFree(ctx->chain_acc[c]);
@@ -649,13 +654,21 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     a.total_w = (float)(sample_begin + sample_count); a.inv_total_w = 1.0f / a.total_w;
     // Grid: no more waves than are resident at once.  Overlapping launches fill the chip together, so each
     // can be smaller: fewer waves means more pixels per lane (lanes that regenerate instead of idling until
-    // the launch ends).  Aim at >= 7 pixels per lane, but keep the chains' grids together ~1.35x the
-    // resident capacity.  (measured at 720p, 1 spp: 3 x 1536 blocks 6.3, 3 x 768 6.7, 4 x 512 6.9 Gsamples/s)
+    // the launch ends).  The chains' grids together are ~1.35x the resident capacity; a launch with enough
+    // work to keep its lanes regenerating for long (>= 14 samples per lane) gets as many waves as that allows.
+    // (measured at 720p, 1 spp, Gsamples/s: 4 x 518 blocks 8.5, 6 x 345 9.3, 8 x 259 9.5, 8 x 514 8.6;
+    //  4K, 16 spp: 8 x 1536 11.0, 8 x 400 8.6)
+    // (Long launches on more chains than the ~4 the command processor keeps active at once underfill the chip
+    //  with small grids: `random4096` at 720p, 8 x 259 blocks 168 Msamples/s, 4 x 518 226.  A sample of a
+    //  large scene therefore counts as many: its brute-force cost relative to the Cornell box's.)
+    const DevSceneF& f = ctx->sf;
+    const uint32_t serial_cost = 25u * (uint32_t)f.ns + 7u * (uint32_t)(f.nax + f.nay + f.naz) + 13u * (uint32_t)f.npg + 35u * (uint32_t)f.nt;
     uint32_t cap = resident;
     if (pipelined) {
-        const uint32_t by_work = (uint32_t)(((uint64_t)ctx->width * ctx->height) / (256u * 7u));
+        const uint64_t weight = serial_cost > 400u ? serial_cost / 400u : 1u;
+        const uint64_t by_work = ((uint64_t)ctx->width * ctx->height * sample_count * weight) / (256u * 14u);
         const uint32_t by_fill = (resident * 27u) / (20u * ctx->flight);
-        const uint32_t want = by_work > by_fill ? by_work : by_fill;
+        const uint32_t want = by_work > by_fill ? (by_work > resident ? resident : (uint32_t)by_work) : by_fill;
         if (want < cap) cap = want;
     }
     // work unit = 4x4 pixels; a ticket is at least units_per_grab of them.  Default: aim at >= 8
@@ -668,8 +681,7 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     uint32_t blocks = (units / a.units_per_grab + 3u) / 4u;  // no more waves than tickets ...
     if (blocks > cap) blocks = cap;                          // ... and no more than the cap
     {   // lane-parallel intersection pays while (rays in flight) x (per-ray cost) < cost of one 64-ray pass
-        const DevSceneF& f = ctx->sf;
-        const uint32_t serial = 25u * (uint32_t)f.ns + 7u * (uint32_t)(f.nax + f.nay + f.naz) + 13u * (uint32_t)f.npg + 35u * (uint32_t)f.nt;
+        const uint32_t serial = serial_cost;
         const uint32_t per_ray = 40u + 27u * (((uint32_t)f.ns + 63u) / 64u) + 15u * (((uint32_t)f.np + 63u) / 64u) + 37u * (((uint32_t)f.nt + 63u) / 64u);
         uint32_t few = serial / per_ray;
         a.few_max = few > 48u ? 48u : few;
@@ -694,9 +706,7 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     } else a.trace = nullptr;
     HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, blocks, stream));
     if (display_pass)
-        HIP_TRY(pt_launch_display(ctx->accum, ctx->chain_acc[1], ctx->flight > 2 ? ctx->chain_acc[2] : nullptr,
-                                  ctx->flight > 3 ? ctx->chain_acc[3] : nullptr, (uint32_t*)ctx->display,
-                                  ctx->width * ctx->height, stream));
+        HIP_TRY(pt_launch_display(chain_accs(ctx, ctx->flight), (uint32_t*)ctx->display, ctx->width * ctx->height, stream));
     if (pipelined) {
         HIP_TRY(hipEventRecord(ctx->chain_done[chain], stream));
         ctx->burst++;
@@ -766,7 +776,7 @@ int pt_flush(PtContext* ctx) {
 
 int pt_set_frames_in_flight(PtContext* ctx, uint32_t n) {
     if (int rc = use(ctx)) return rc;
-    if (n < 1 || n > 4) return fail(PT_ERR_INVALID, "frames in flight must be 1..4, got %u", n);
+    if (n < 1 || n > PT_MAX_CHAINS) return fail(PT_ERR_INVALID, "frames in flight must be 1..%u, got %u", PT_MAX_CHAINS, n);
     if (int rc = join_chains(ctx)) return rc;
     ctx->flight = n;
     return PT_OK;

@@ -95,9 +95,14 @@ hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArg
 hipError_t pt_path_resident_blocks(bool nee, bool count, int device, uint32_t* blocks);
 hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint32_t acc_mode, uint32_t mode,
                              hipStream_t stream);
-hipError_t pt_launch_merge(float4* acc0, float4* c1, float4* c2, float4* c3, uint32_t npix, hipStream_t stream);
-hipError_t pt_launch_display(const float4* c0, const float4* c1, const float4* c2, const float4* c3, uint32_t* rgba,
-                             uint32_t npix, hipStream_t stream);
+// frames in flight: the accumulators of the chains of a context ([0] = the context's own / bound buffer), by value
+constexpr uint32_t PT_MAX_CHAINS = 8;
+struct ChainAccs {
+    float4* acc[PT_MAX_CHAINS];
+    uint32_t n;  // chains in use, 1..PT_MAX_CHAINS
+};
+hipError_t pt_launch_merge(const ChainAccs& chains, uint32_t npix, hipStream_t stream);
+hipError_t pt_launch_display(const ChainAccs& chains, uint32_t* rgba, uint32_t npix, hipStream_t stream);
 hipError_t pt_launch_valu_peak(float* sink, uint32_t packed, uint32_t iters, uint32_t blocks, hipStream_t stream);
 hipError_t pt_launch_primary_ids(const DevSceneD& sc, const DevCamD& cam, uint32_t* obj, uint32_t* mat,
                                  hipStream_t stream);

@@ -751,17 +751,18 @@ __global__ __launch_bounds__(256) void pt_resolve_kernel(const float4* __restric
 
 // ------------------------------------------------------------------------------------------
 // Frames in flight: folds the chains' accumulators into the first one in a fixed order
-// (acc0 + acc1 + acc2 + acc3, so the result is reproducible) and clears the others.
-__global__ __launch_bounds__(256) void pt_merge_kernel(float4* __restrict__ acc0, float4* __restrict__ c1,
-                                                       float4* __restrict__ c2, float4* __restrict__ c3, uint32_t npix) {
+// (acc0 + acc1 + acc2 + ..., so the result is reproducible) and clears the others.
+__global__ __launch_bounds__(256) void pt_merge_kernel(const ChainAccs chains, uint32_t npix) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= npix) return;
-    float4 a = acc0[p];
+    float4 a = chains.acc[0][p];
     const float4 zero = make_float4(0, 0, 0, 0);
-    if (c1) { const float4 q = c1[p]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; c1[p] = zero; }
-    if (c2) { const float4 q = c2[p]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; c2[p] = zero; }
-    if (c3) { const float4 q = c3[p]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; c3[p] = zero; }
-    acc0[p] = a;
+    for (uint32_t c = 1; c < chains.n; ++c) {  // wave-uniform trip count; the loads of one lane are independent
+        const float4 q = chains.acc[c][p];
+        a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+        chains.acc[c][p] = zero;
+    }
+    chains.acc[0][p] = a;
 }
 
 // Frames in flight: the display of a frame, as a pass of its own behind the frame's launch on the chain's
@@ -769,15 +770,14 @@ __global__ __launch_bounds__(256) void pt_merge_kernel(float4* __restrict__ acc0
 // before or after its 16-B store, a consistent mean either way; display only).  The path launches are VALU-
 // bound and leave HBM idle, so these 68 B per pixel ride along; fused into the path kernel the same reads
 // sit in the regeneration block at low lane occupancy and cost 7 % of the frame rate.
-__global__ __launch_bounds__(256) void pt_display_kernel(const float4* __restrict__ c0, const float4* __restrict__ c1,
-                                                         const float4* __restrict__ c2, const float4* __restrict__ c3,
-                                                         uint32_t* __restrict__ rgba, uint32_t npix) {
+__global__ __launch_bounds__(256) void pt_display_kernel(const ChainAccs chains, uint32_t* __restrict__ rgba, uint32_t npix) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= npix) return;
-    float4 a = c0[p];
-    if (c1) { const float4 q = c1[p]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
-    if (c2) { const float4 q = c2[p]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
-    if (c3) { const float4 q = c3[p]; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
+    float4 a = chains.acc[0][p];
+    for (uint32_t c = 1; c < chains.n; ++c) {
+        const float4 q = chains.acc[c][p];
+        a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+    }
     const float inv = a.w > 0.0f ? 1.0f / a.w : 0.0f;
     rgba[p] = pack_rgba8_cuda(a.x * inv, a.y * inv, a.z * inv);
 }
@@ -859,14 +859,13 @@ hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint
     return hipGetLastError();
 }
 
-hipError_t pt_launch_merge(float4* acc0, float4* c1, float4* c2, float4* c3, uint32_t npix, hipStream_t stream) {
-    hipLaunchKernelGGL(pt_merge_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, acc0, c1, c2, c3, npix);
+hipError_t pt_launch_merge(const ChainAccs& chains, uint32_t npix, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_merge_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, chains, npix);
     return hipGetLastError();
 }
 
-hipError_t pt_launch_display(const float4* c0, const float4* c1, const float4* c2, const float4* c3, uint32_t* rgba,
-                             uint32_t npix, hipStream_t stream) {
-    hipLaunchKernelGGL(pt_display_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, c0, c1, c2, c3, rgba, npix);
+hipError_t pt_launch_display(const ChainAccs& chains, uint32_t* rgba, uint32_t npix, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_display_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, chains, rgba, npix);
     return hipGetLastError();
 }
 

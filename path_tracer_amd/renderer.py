@@ -78,7 +78,7 @@ class Renderer:
         check(self._L.pt_use_own_stream(self._ctx))
 
     def set_frames_in_flight(self, n: int):
-        """1..4 consecutive sum-mode launches overlap on internal streams (include/pt.h)."""
+        """1..8 consecutive sum-mode launches overlap on internal streams (include/pt.h)."""
         check(self._L.pt_set_frames_in_flight(self._ctx, n))
 
     def reduce(self, nccl_comm, root: int = 0):

@@ -401,7 +401,7 @@ def test_stream_switch_keeps_queued_work_ordered(gpu):
 
 
 # ------------------------------------------------------------------ frames in flight ---
-@pytest.mark.parametrize("n", [2, 3, 4])
+@pytest.mark.parametrize("n", [2, 3, 4, 8])
 def test_frames_in_flight_match_serial(gpu, n):
     """Launches overlapped on n chains hold the same samples as serial launches: every pixel's
     count is exact, the sums differ only by float summation order, and the result does not
@@ -520,7 +520,7 @@ def test_frames_in_flight_random_call_sequences(gpu):
                 gpu.render(next_sample, n, abi.render_params(fused_rgba8=int(rng.integers(0, 2)), max_depth=6))
                 next_sample += n; expected += n
             elif op == 5:
-                gpu.set_frames_in_flight(int(rng.integers(1, 5)))
+                gpu.set_frames_in_flight(int(rng.integers(1, 9)))
             elif op == 6:
                 gpu.flush()
             elif op == 7:

@@ -25,5 +25,5 @@ def run(nctx, flight, w, h, spp, launches, blocks):
     for r in rs: r.close()
     return round(best, 1)
 for (w, h, spp, n) in ((1280, 720, 1, 480), (1280, 720, 16, 48)):
-    for nctx, flight, blocks in ((1, 4, 0), (2, 3, 350), (2, 4, 0), (2, 4, 260), (2, 4, 330), (3, 4, 175), (3, 4, 230)):
+    for nctx, flight, blocks in ((1, 4, 0), (2, 3, 350), (2, 3, 300), (2, 4, 260), (2, 4, 220), (3, 2, 350), (3, 3, 230)):
         print(w, h, spp, "contexts", nctx, "flight", flight, "blocks", blocks, run(nctx, flight, w, h, spp, n, blocks), flush=True)

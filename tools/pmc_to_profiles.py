@@ -32,7 +32,7 @@ out["cornell_720p_progressive_1spp"] = {"hbm_bytes_per_launch": round(fetch + wr
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 for name in ("bench.json", "bench_serial.json", "bench_4k.json"):
     shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
-for sub, name in (("trace_default", "kernel_stats_flight4"), ("trace_serial", "kernel_stats_serial")):
+for sub, name in (("trace_default", "kernel_stats_flight8"), ("trace_serial", "kernel_stats_serial")):
     f = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)[0]
     shutil.copy(f, os.path.join(dst, f"{tag}_{name}.csv"))
 print(json.dumps(out["derived"], indent=1)); print(out["cornell_720p_progressive_1spp"])

@@ -11,7 +11,7 @@ B=$R/bench.py
 timeout -k 10 300 python3 -u $B > $O/bench.json 2> $O/bench.err || { echo "bench failed"; tail -5 $O/bench.err; exit 1; }
 timeout -k 10 300 python3 -u $B --frames-in-flight 1 --cpu-seconds 0 > $O/bench_serial.json 2> $O/bench_serial.err || { echo "serial bench failed"; exit 1; }
 timeout -k 10 300 python3 -u $B --workload cornell_4k_16spp_per_step --steps 24 --warmup 4 --cpu-seconds 0 > $O/bench_4k.json 2> $O/bench_4k.err || { echo "4k bench failed"; exit 1; }
-# kernel trace + stats of the same bench command (default = frames in flight 4, and strictly serial)
+# kernel trace + stats of the same bench command (default = frames in flight 8, and strictly serial)
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -- python3 $B --cpu-seconds 0 > $O/trace_default.log 2>&1 || { echo "trace default failed"; tail -5 $O/trace_default.log; exit 1; }
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_serial -- python3 $B --frames-in-flight 1 --cpu-seconds 0 > $O/trace_serial.log 2>&1 || { echo "trace serial failed"; exit 1; }
 # PMC passes (each its own run; <= 8 SQ / 4 TCC counters per pass), serial launches so that per-dispatch numbers are per launch

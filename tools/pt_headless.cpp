@@ -18,7 +18,7 @@ static void usage() {
         "usage: pt_headless [--scene cuda_default|cpu_default|glass_stress|random4096] [--width W] [--height H]\n"
         "                   [--spp N] [--spp-per-launch K] [--max-depth D] [--integrator path|direct] [--seed S]\n"
         "                   [--mis] [--light-colour] [--device I] [--resume raw] [--out image.ppm] [--raw accum.f32]\n"
-        "                   [--frames-in-flight 1..4]  overlap consecutive launches (progressive rendering at few spp per launch)\n"
+        "                   [--frames-in-flight 1..8]  overlap consecutive launches (progressive rendering at few spp per launch)\n"
         "                   [--script camera.txt]   lines: <frames> <mouse_dx> <mouse_dy> <keys: wasd u(p) c(down) or ->\n"
         "                                           (the CPU app's frame loop, main.cpp:153-237, 1 spp per frame;\n"
         "                                           --out then names a printf pattern, one PPM per script line)");
