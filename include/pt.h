@@ -235,7 +235,8 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
  * run to run; it differs from the n = 1 image only by float summation order.
  * A fused display (fused_rgba8) is then made by a pass of its own behind each
  * launch; written while other launches are in flight it shows, per pixel, a
- * mean that may or may not include their newest sample.
+ * mean that may or may not include their newest sample.  Folding the chains
+ * redoes it from the folded sums, so a display read through the library is exact.
  * n > 3 needs more hardware queues than HIP's default of 4 per process:
  * GPU_MAX_HW_QUEUES >= n + 4 in the environment before HIP initialises (16 for
  * n = 8).  Chains that share a queue serialise: with the default, n = 4 is

@@ -82,6 +82,7 @@ struct PtContext {
     float4* chain_acc[PT_MAX_CHAINS] = {};  // [0] unused (= accum)
     size_t chain_acc_pixels = 0;
     uint32_t burst = 0;                // launches since the chains were last joined
+    bool burst_displayed = false;      // some launch of the burst made a display pass
     uint64_t* trace = nullptr;         // PT_AMD_TRACE=<file>: per-wave timeline of the last launch (PT_TRACE kernel builds)
     size_t trace_waves = 0;
     uint32_t resident_blocks[4] = {0, 0, 0, 0};  // per kernel variant (nee, count)
@@ -143,6 +144,11 @@ int join_chains(PtContext* ctx) {
         HIP_TRY(pt_launch_merge(chain_accs(ctx, used), ctx->width * ctx->height, ctx->stream));
     }
     ctx->burst = 0;
+    if (ctx->burst_displayed) {
+        // the display passes of the burst were previews; the folded sums give the exact image
+        ctx->burst_displayed = false;
+        HIP_TRY(pt_launch_resolve(ctx->accum, ctx->display, ctx->width * ctx->height, PT_ACC_SUM, PT_RESOLVE_RGBA8_CUDA, ctx->stream));
+    }
     return PT_OK;
 }
 
@@ -705,6 +711,7 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
         a.trace = ctx->trace;
     } else a.trace = nullptr;
     HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, blocks, stream));
+    if (display_pass) ctx->burst_displayed = true;
     if (display_pass)
         HIP_TRY(pt_launch_display(chain_accs(ctx, ctx->flight), (uint32_t*)ctx->display, ctx->width * ctx->height, stream));
     if (pipelined) {
