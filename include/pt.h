@@ -247,7 +247,8 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
  * of at most 2^22 pixels a PT_ACC_SUM path call is therefore executed as several
  * launches of 8..32 samples on the internal streams: with n > 1, calls for more
  * than 48 samples join the open burst; with n = 1, a call for 12 samples or
- * more is a burst of its own on three chains, folded (and, with fused_rgba8,
+ * more is a burst of its own on three chains (GPU_MAX_HW_QUEUES - 4 of them
+ * when the environment grants more, up to 8), folded (and, with fused_rgba8,
  * resolved) before pt_render returns, so nothing stays in flight.  The partition
  * depends only on the call's arguments: the image is reproducible and equals
  * the single launch's up to float summation order.  (Environment variable

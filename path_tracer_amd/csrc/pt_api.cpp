@@ -83,6 +83,7 @@ struct PtContext {
     size_t chain_acc_pixels = 0;
     uint32_t burst = 0;                // launches since the chains were last joined
     bool burst_displayed = false;      // some launch of the burst made a display pass
+    uint32_t burst_chains = 3;         // chains of a burst that pt_render opens by itself: GPU_MAX_HW_QUEUES - 4, 3..8
     uint64_t* trace = nullptr;         // PT_AMD_TRACE=<file>: per-wave timeline of the last launch (PT_TRACE kernel builds)
     size_t trace_waves = 0;
     uint32_t resident_blocks[4] = {0, 0, 0, 0};  // per kernel variant (nee, count)
@@ -237,6 +238,10 @@ int pt_create(int device_id, PtContext** out) {
     if (const char* e = getenv("PT_AMD_MAX_BLOCKS")) ctx->knob_max_blocks = atoi(e);
     if (const char* e = getenv("PT_AMD_TRACE")) ctx->knob_trace = e;
     if (const char* e = getenv("PT_AMD_CHUNK")) ctx->knob_chunk = atoi(e);
+    if (const char* e = getenv("GPU_MAX_HW_QUEUES")) {  // HIP reads the same variable when it initialises
+        const int q = atoi(e) - 4;
+        ctx->burst_chains = q < 3 ? 3u : (q > (int)PT_MAX_CHAINS ? PT_MAX_CHAINS : (uint32_t)q);
+    }
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(PT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     ctx->stream = ctx->own_stream;
@@ -594,7 +599,7 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     // launch at 720p runs at 6.1 Gsamples/s, the same samples in 32-sample launches dealt to the chains
     // at 10.  A call for more than 48 samples (12 without frames in flight) is therefore cut into such launches.  (4K launches hold 21
     // pixels per lane and are left whole.)  With frames in flight the launches join the open burst; without,
-    // the call is a burst of its own on three chains, folded before it returns, and a fused display is made
+    // the call is a burst of its own on three chains (more when GPU_MAX_HW_QUEUES allows), folded before it returns, and a fused display is made
     // from the folded sums.  The partition depends only on the call's arguments: reproducible, and equal to
     // the single launch up to float summation order.
     // (Three chains at 4 samples per launch already beat one serial launch: 9.6 against 5.9 Gsamples/s.)
@@ -609,7 +614,7 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
         const uint32_t user_flight = ctx->flight;
         PtRenderParams sub = *prm;
         if (!pipelined) {
-            ctx->flight = 3;  // a fourth chain pays only when the process has more than HIP's default 4 hardware queues
+            ctx->flight = ctx->burst_chains;  // 3 with HIP's default 4 hardware queues (more chains would share a queue)
             sub.fused_rgba8 = 0;
         }
         uint32_t begin = sample_begin, left = sample_count;

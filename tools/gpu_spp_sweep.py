@@ -12,7 +12,7 @@ for name, (w, h) in {"720p": (1280, 720), "1080p": (1920, 1080), "360p": (640, 3
     r.set_scene(sc); r.set_camera(cam)
     for flight in (1,):
         r.set_frames_in_flight(flight)
-        for spl in (16, 32, 64, 128, 256, 512, 2048):
+        for spl in (16, 64, 256, 2048):
             total = 1024 if name != "4k" else 256
             launches = max(1, total // spl)
             r.reset(); r.render(0, spl, abi.render_params()); r.sync()
