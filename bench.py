@@ -52,6 +52,9 @@ def main() -> int:
     ap.add_argument("--frames-in-flight", type=int, default=8, choices=tuple(range(1, 9)),
                     help="consecutive launches overlapped on internal streams (include/pt.h); 1 = strictly serial launches")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks over gloo, all on GPU 0: exercises the multi-rank code path on a one-GPU box (the "
+                         "number means nothing)")
     args = ap.parse_args()
 
     # frames in flight need one hardware queue per chain plus a few for the launch stream and torch's own;
@@ -69,20 +72,32 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    def stage(msg):
+        if os.environ.get("BENCH_TRACE"):  # a file name prefix: one line per stage and rank
+            with open(f"{os.environ['BENCH_TRACE']}_rank{rank}.log", "a") as f:
+                f.write(f"{time.perf_counter():.3f} {msg}\n")
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}`", file=sys.stderr)
             return 2
         args.gpus = world
+    rehearsal = args.rehearse_on_one_gpu
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     scene_name, W, H, spp, max_depth = WORKLOADS[args.workload]
     scene, cam = scenes.builtin(scene_name, W, H)
     flags = abi.FLAG_NEE_MIS if args.mis else 0
     params = abi.render_params(max_depth=max_depth, flags=flags, fused_rgba8=1, pixels_per_wave=args.pixels_per_wave)
 
+    stage("process group up")
     r = Renderer(local_rank)
     r.use_torch_stream()
     r.set_scene(scene)
@@ -96,15 +111,20 @@ def main() -> int:
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize()
+            dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
+    stage("set-up done")
     for s0, n in sched[:Wm]:
         r.render(s0, n, params)
     r.flush()
+    stage("warm-up enqueued")
     if world > 1:  # warm the collective too
         reduce_accum(accum.clone())
+        stage("collective warmed")
     barrier()
+    stage("timed region starts")
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -118,6 +138,14 @@ def main() -> int:
         r.resolve(abi.RESOLVE_RGBA8_CUDA)
     barrier()
     elapsed = time.perf_counter() - t0
+    stage("timed region done")
+    if rank == 0:
+        # every pixel now holds the samples of every rank (warm-up frames included), each once
+        want_w = float(world * (Wm + K) * spp)
+        w_min, w_max = float(accum[..., 3].min()), float(accum[..., 3].max())
+        if w_min != want_w or w_max != want_w:
+            print(f"bench.py: accumulation buffer holds {w_min}..{w_max} samples per pixel, expected {want_w}", file=sys.stderr)
+            return 3
     # HIP events on the launch stream around the K launches (the chains fork from and join this stream):
     # the time per launch the chip needed, with `frames_in_flight` launches overlapping
     kernel_ms = ev0.elapsed_time(ev1) / K
@@ -170,7 +198,7 @@ def main() -> int:
             "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "spp_per_step": spp,
                        "max_depth": max_depth, "integrator": "path+nee_mis" if args.mis else "path",
                        "accumulate": "sum+fused_rgba8", "frames_in_flight": args.frames_in_flight, "parallelism": f"sample_split{world}" if world > 1 else "single",
-                       "reduce": "rccl_reduce_sum_once" if world > 1 else None},
+                       "reduce": ("gloo_rehearsal_on_one_gpu" if rehearsal else "rccl_reduce_sum_once") if world > 1 else None},
             "mrays_per_s": round(value * rays_per_sample, 1), "rays_per_sample": round(rays_per_sample, 4),
             "roofline": {"bound": "valu", "kernel": "pt_path_kernel", "achieved": round(achieved, 4),
                          "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5),
@@ -183,7 +211,7 @@ def main() -> int:
         if world == 1 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(scene, cam, params, spp, args.cpu_seconds)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
