@@ -8,6 +8,8 @@ A "step" is one frame: one launch of the path kernel over all 921 600 pixels.
   N > 1 : sample-split, weak scaling — every rank renders K frames of 1 spp for its own
           disjoint sample indices, then the float4 accumulation buffers are summed once with an
           RCCL reduce to rank 0 (inside the timed region), which resolves the image.
+          `--scaling strong` divides the K steps among the ranks instead (BASELINE config 3, e.g.
+          `--workload cornell_4k_16spp_per_step --steps 64` = 4K at 1024 spp split N ways).
 Scene, camera and accumulation buffer are resident in HBM before the timed region; the
 display buffer is never copied to the host inside it (the reference's per-frame D2H + XPutImage
 is the X11 path, out of scope).
@@ -52,6 +54,9 @@ def main() -> int:
     ap.add_argument("--frames-in-flight", type=int, default=8, choices=tuple(range(1, 9)),
                     help="consecutive launches overlapped on internal streams (include/pt.h); 1 = strictly serial launches")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak: every rank renders K steps (default, the driver's contract); strong: the K steps are "
+                         "divided among the ranks (BASELINE config 3: a fixed sample count split across the GPUs)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks over gloo, all on GPU 0: exercises the multi-rank code path on a one-GPU box (the "
                          "number means nothing)")
@@ -108,6 +113,12 @@ def main() -> int:
 
     K, Wm = args.steps, args.warmup
     sched = progressive_schedule(0, Wm + K, world, rank, spp)
+    if args.scaling == "strong" and world > 1:
+        # warm-up as above; then this rank's contiguous share of the K timed steps
+        from path_tracer_amd.distributed import partition
+        first = Wm * world * spp
+        begin, count = partition(K, world, rank)
+        sched = sched[:Wm] + [(first + (begin + g) * spp, spp) for g in range(count)]
 
     def barrier():
         if world > 1:
@@ -141,19 +152,20 @@ def main() -> int:
     stage("timed region done")
     if rank == 0:
         # every pixel now holds the samples of every rank (warm-up frames included), each once
-        want_w = float(world * (Wm + K) * spp)
+        want_w = float((world * Wm + (K if args.scaling == "strong" else world * K)) * spp)
         w_min, w_max = float(accum[..., 3].min()), float(accum[..., 3].max())
         if w_min != want_w or w_max != want_w:
             print(f"bench.py: accumulation buffer holds {w_min}..{w_max} samples per pixel, expected {want_w}", file=sys.stderr)
             return 3
     # HIP events on the launch stream around the K launches (the chains fork from and join this stream):
     # the time per launch the chip needed, with `frames_in_flight` launches overlapping
-    kernel_ms = ev0.elapsed_time(ev1) / K
+    my_steps = len(sched) - Wm
+    kernel_ms = ev0.elapsed_time(ev1) / max(my_steps, 1)
     # the same launches strictly one after another, for comparison with rocprofv3's per-dispatch durations
     serial_ms = kernel_ms
     if args.frames_in_flight > 1:
         r.set_frames_in_flight(1)
-        n_serial = min(K, 128)
+        n_serial = min(my_steps, 128)
         torch.cuda.synchronize()
         ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev2.record()
@@ -161,14 +173,15 @@ def main() -> int:
             r.render(s0, n, params)
         ev3.record()
         torch.cuda.synchronize()
-        serial_ms = ev2.elapsed_time(ev3) / n_serial
+        serial_ms = ev2.elapsed_time(ev3) / max(n_serial, 1)
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
     samples_per_step = W * H * spp
-    value = world * K * samples_per_step / elapsed / 1e6
+    total_steps = K if args.scaling == "strong" else world * K
+    value = total_steps * samples_per_step / elapsed / 1e6
 
     result = None
     if rank == 0:
@@ -177,7 +190,7 @@ def main() -> int:
         r.reset()
         r.reset_counters()
         cp = abi.render_params(max_depth=max_depth, flags=flags | abi.FLAG_COUNTERS, pixels_per_wave=args.pixels_per_wave)
-        n_cnt = min(K, 8)
+        n_cnt = max(1, min(my_steps, 8))
         for s0, n in sched[Wm:Wm + n_cnt]:
             r.render(s0, n, cp)
         cnt = r.counters().as_dict()
@@ -194,7 +207,7 @@ def main() -> int:
         result = {
             "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
             "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "spp_per_step": spp,
                        "max_depth": max_depth, "integrator": "path+nee_mis" if args.mis else "path",
                        "accumulate": "sum+fused_rgba8", "frames_in_flight": args.frames_in_flight, "parallelism": f"sample_split{world}" if world > 1 else "single",
