@@ -10,6 +10,7 @@ Bars (north_star / task ③):
   * RGBA8 / PPM packing: bit-exact on the same accumulation buffer.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -17,6 +18,7 @@ import pytest
 from path_tracer_amd import abi, scenes
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -1008,3 +1010,26 @@ def test_full_size_4k_smoke(gpu):
     small = scenes.cuda_default(64, 36)
     gpu.set_scene(small[0])
     gpu.set_camera(small[1])
+
+
+def test_bench_line_contract():
+    """bench.py prints one JSON line with the contract's keys, the roofline and the CPU baseline."""
+    import json
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "48", "--warmup", "8", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-800:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 48 and d["warmup"] == 8 and d["value"] > 0 and d["vs_baseline"] is None
+    assert d["config"]["workload"] == "cornell_720p_progressive_1spp" and d["dtype"] == "f32"
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1 and r["unit"] == "TFLOP/s"
+    assert abs(d["value"] - 1280 * 720 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == d["unit"]
