@@ -217,6 +217,174 @@ inline uint32_t hash32(uint32_t x) {  // counter-RNG finaliser, DESIGN.md §RNG
     return x;
 }
 
+
+// Frames in flight are for sums only (a running mean is a recurrence on one buffer), and not while a
+// per-launch trace is being written.
+bool can_overlap(const PtContext* ctx, const PtRenderParams* prm) {
+    return prm->acc_mode == PT_ACC_SUM && ctx->knob_trace.empty();
+}
+
+// Samples per launch when a call is cut into launches (0: never cut).
+uint32_t part_size(const PtContext* ctx, uint32_t sample_count, bool pipelined) {
+    if (ctx->knob_chunk >= 0) return (uint32_t)ctx->knob_chunk;
+    if (pipelined) return 32u;
+    // a burst of its own wants about four launches per chain to amortise its tail (8..32 samples each)
+    const uint32_t c = (sample_count + 11u) / 12u;
+    return c < 8u ? 8u : (c > 32u ? 32u : c);
+}
+
+// A pixel belongs to one lane for the whole launch, so a launch with many samples per pixel and few pixels
+// per lane (2.3 at 720p) ends with most lanes idle while the last pixels finish: one 256-sample launch at
+// 720p runs at 6.1 Gsamples/s, the same samples in 32-sample launches dealt to the chains at 10.  A call for
+// more than 48 samples (12 without frames in flight: three chains at 4 samples per launch already beat one
+// serial launch, 9.6 against 5.9 Gsamples/s) is therefore cut into such launches.  4K launches hold 21
+// pixels per lane and are left whole.
+bool wants_parts(const PtContext* ctx, uint32_t sample_count, const PtRenderParams* prm) {
+    if (!can_overlap(ctx, prm) || (uint64_t)ctx->width * ctx->height > (1ull << 22)) return false;
+    const bool pipelined = ctx->flight > 1;
+    const uint32_t part = part_size(ctx, sample_count, pipelined);
+    return part > 0 && sample_count >= (pipelined ? part + part / 2u + 1u : 12u);
+}
+
+int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm);
+
+// With frames in flight the launches join the open burst; without, the call is a burst of its own on
+// `burst_chains` chains, folded before it returns, and a fused display is made from the folded sums.  The
+// partition depends only on the call's arguments: reproducible, and equal to the single launch up to float
+// summation order.
+int render_in_parts(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm) {
+    const bool pipelined = ctx->flight > 1;
+    const uint32_t part = part_size(ctx, sample_count, pipelined);
+    uint32_t parts = (sample_count + part - 1u) / part;
+    if (!pipelined && parts < 3u) parts = 3u;  // one launch per chain at least
+    const uint32_t user_flight = ctx->flight;
+    PtRenderParams sub = *prm;
+    if (!pipelined) {
+        ctx->flight = ctx->burst_chains;
+        sub.fused_rgba8 = 0;
+    }
+    uint32_t begin = sample_begin, left = sample_count;
+    int rc = PT_OK;
+    for (uint32_t k = 0; k < parts && rc == PT_OK; ++k) {
+        const uint32_t n = (left + (parts - k) - 1u) / (parts - k);  // as equal as integers allow
+        rc = launch_path(ctx, begin, n, &sub);
+        begin += n; left -= n;
+    }
+    if (!pipelined) {
+        const int rj = join_chains(ctx);
+        ctx->flight = user_flight;
+        if (rc == PT_OK) rc = rj;
+        if (rc == PT_OK && prm->fused_rgba8) rc = pt_resolve(ctx, PT_RESOLVE_RGBA8_CUDA);
+    }
+    return rc;
+}
+
+// One launch of the path kernel for samples [sample_begin, sample_begin + sample_count) (arguments validated by pt_render).
+int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm) {
+    const bool pipelined = ctx->flight > 1 && can_overlap(ctx, prm);
+    uint32_t chain = 0;
+    hipStream_t stream = ctx->stream;
+    if (pipelined) {
+        if (ctx->burst == 0) {
+            if (int rc = prepare_chains(ctx)) return rc;
+            HIP_TRY(hipEventRecord(ctx->fork_event, ctx->stream));
+        }
+        chain = ctx->burst % ctx->flight;
+        stream = ctx->chain_stream[chain];
+        if (ctx->burst < ctx->flight) HIP_TRY(hipStreamWaitEvent(stream, ctx->fork_event, 0));  // first launch of this chain in the burst
+    } else {
+        if (int rc = join_chains(ctx)) return rc;
+    }
+    PathArgs a{};
+    a.accum = chain == 0 ? ctx->accum : ctx->chain_acc[chain];
+    // a launch that overlaps others displays in a pass of its own behind it (pt_display_kernel): the mean over all chains
+    const bool display_pass = pipelined && prm->fused_rgba8;
+    a.rgba = (prm->fused_rgba8 && !display_pass) ? (uint32_t*)ctx->display : nullptr;
+    a.counters = (prm->flags & PT_FLAG_COUNTERS) ? ctx->counters : nullptr;
+    a.s0 = sample_begin; a.count = sample_count;
+    a.max_depth = prm->max_depth; a.rr_depth = prm->rr_depth; a.seed_hash = hash32(prm->seed);
+    a.light_colour = (prm->flags & PT_FLAG_LIGHT_COLOUR) ? 1u : 0u;
+    a.acc_mode = prm->acc_mode;
+    a.mean_t = 1.0f / (float)(sample_begin + 1u);  // :299
+    a.tiles_x = (ctx->width + 7u) / 8u; a.tiles_y = (ctx->height + 7u) / 8u;
+    a.num_tiles = a.tiles_x * a.tiles_y;
+    const bool nee = (prm->flags & PT_FLAG_NEE_MIS) != 0, cnt = (prm->flags & PT_FLAG_COUNTERS) != 0;
+    uint32_t& resident = ctx->resident_blocks[(nee ? 2 : 0) + (cnt ? 1 : 0)];
+    if (resident == 0) HIP_TRY(pt_path_resident_blocks(nee, cnt, ctx->device, &resident));
+    a.inv_tiles_x = 1.0f / (float)a.tiles_x;
+    a.total_w = (float)(sample_begin + sample_count); a.inv_total_w = 1.0f / a.total_w;
+    // Grid: no more waves than are resident at once.  Overlapping launches fill the chip together, so each
+    // can be smaller: fewer waves means more pixels per lane (lanes that regenerate instead of idling until
+    // the launch ends).  The chains' grids together are ~1.35x the resident capacity; a launch with enough
+    // work to keep its lanes regenerating for long (>= 14 samples per lane) gets as many waves as that allows.
+    // (measured at 720p, 1 spp, Gsamples/s: 4 x 518 blocks 8.5, 6 x 345 9.3, 8 x 259 9.5, 8 x 514 8.6;
+    //  4K, 16 spp: 8 x 1536 11.0, 8 x 400 8.6)
+    // (Long launches on more chains than the ~4 the command processor keeps active at once underfill the chip
+    //  with small grids: `random4096` at 720p, 8 x 259 blocks 168 Msamples/s, 4 x 518 226.  A sample of a
+    //  large scene therefore counts as many: its brute-force cost relative to the Cornell box's.)
+    const DevSceneF& f = ctx->sf;
+    const uint32_t serial_cost = 25u * (uint32_t)f.ns + 7u * (uint32_t)(f.nax + f.nay + f.naz) + 13u * (uint32_t)f.npg + 35u * (uint32_t)f.nt;
+    uint32_t cap = resident;
+    if (pipelined) {
+        const uint64_t weight = serial_cost > 400u ? serial_cost / 400u : 1u;
+        const uint64_t by_work = ((uint64_t)ctx->width * ctx->height * sample_count * weight) / (256u * 14u);
+        const uint32_t by_fill = (resident * 27u) / (20u * ctx->flight);
+        const uint32_t want = by_work > by_fill ? (by_work > resident ? resident : (uint32_t)by_work) : by_fill;
+        if (want < cap) cap = want;
+    }
+    // work unit = 4x4 pixels; a ticket is at least units_per_grab of them.  Default: aim at >= 8
+    // tickets per wave of the grid, but never more than one 8x8 tile per ticket.
+    const uint32_t units = a.num_tiles * 4u;
+    uint32_t upg;
+    if (prm->pixels_per_wave) upg = (prm->pixels_per_wave + 15u) / 16u;
+    else { upg = units / (cap * 4u * 8u); upg = upg > 4u ? 4u : upg; }
+    a.units_per_grab = upg < 1u ? 1u : (upg > 65536u ? 65536u : upg);
+    uint32_t blocks = (units / a.units_per_grab + 3u) / 4u;  // no more waves than tickets ...
+    if (blocks > cap) blocks = cap;                          // ... and no more than the cap
+    {   // lane-parallel intersection pays while (rays in flight) x (per-ray cost) < cost of one 64-ray pass
+        const uint32_t serial = serial_cost;
+        const uint32_t per_ray = 40u + 27u * (((uint32_t)f.ns + 63u) / 64u) + 15u * (((uint32_t)f.np + 63u) / 64u) + 37u * (((uint32_t)f.nt + 63u) / 64u);
+        uint32_t few = serial / per_ray;
+        a.few_max = few > 48u ? 48u : few;
+        if (ctx->knob_few_max >= 0) a.few_max = (uint32_t)ctx->knob_few_max;
+    }
+    if (ctx->knob_max_blocks > 0 && blocks > (uint32_t)ctx->knob_max_blocks) blocks = (uint32_t)ctx->knob_max_blocks;
+    if (blocks < 8u) blocks = 8u;                            // every shard needs a block to serve its tiles
+    // launches of one chain are ordered on its stream (chain 0 also serves unpipelined launches, which
+    // join_chains() orders after it): each zeroes the set its successor on the same chain will use
+    a.work_counter = ctx->work_counter + WORK_SET_WORDS * (2u * chain + ctx->work_parity[chain]);
+    a.next_counter = ctx->work_counter + WORK_SET_WORDS * (2u * chain + (ctx->work_parity[chain] ^ 1u));
+    const char* trace_file = ctx->knob_trace.empty() ? nullptr : ctx->knob_trace.c_str();  // kernel-timeline experiments (tools/gpu_trace.py)
+    if (trace_file) {
+        const size_t waves = (size_t)blocks * 4u;
+        if (ctx->trace_waves < waves) {
+            if (ctx->trace) HIP_TRY(hipFree(ctx->trace));
+            HIP_TRY(hipMalloc((void**)&ctx->trace, waves * 128));
+            ctx->trace_waves = waves;
+        }
+        HIP_TRY(hipMemsetAsync(ctx->trace, 0, waves * 128, stream));
+        a.trace = ctx->trace;
+    } else a.trace = nullptr;
+    HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, blocks, stream));
+    if (display_pass) ctx->burst_displayed = true;
+    if (display_pass)
+        HIP_TRY(pt_launch_display(chain_accs(ctx, ctx->flight), (uint32_t*)ctx->display, ctx->width * ctx->height, stream));
+    if (pipelined) {
+        HIP_TRY(hipEventRecord(ctx->chain_done[chain], stream));
+        ctx->burst++;
+    }
+    if (trace_file) {
+        std::vector<uint64_t> host((size_t)blocks * 4u * 16u);
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(host.data(), ctx->trace, host.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(trace_file, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+    }
+    ctx->work_parity[chain] ^= 1u;
+    ctx->last_acc_mode = prm->acc_mode;
+    if (prm->fused_rgba8) ctx->display_bytes = (size_t)ctx->width * ctx->height * 4;
+    return PT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -590,149 +758,8 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
     if (prm->max_depth == 0) return fail(PT_ERR_INVALID, "max_depth must be at least 1");
     if (prm->acc_mode == PT_ACC_RUNNING_MEAN && sample_count != 1)
         return fail(PT_ERR_INVALID, "the running-mean mode adds one sample per launch, like renderKernel");
-    // frames in flight: sums only (a running mean is a recurrence on one buffer), and not while
-    // a per-launch trace is being written
-    const bool can_overlap = prm->acc_mode == PT_ACC_SUM && ctx->knob_trace.empty();
-    const bool pipelined = ctx->flight > 1 && can_overlap;
-    // A pixel belongs to one lane for the whole launch, so a launch with many samples per pixel and few
-    // pixels per lane (2.3 at 720p) ends with most lanes idle while the last pixels finish: one 256-sample
-    // launch at 720p runs at 6.1 Gsamples/s, the same samples in 32-sample launches dealt to the chains
-    // at 10.  A call for more than 48 samples (12 without frames in flight) is therefore cut into such launches.  (4K launches hold 21
-    // pixels per lane and are left whole.)  With frames in flight the launches join the open burst; without,
-    // the call is a burst of its own on three chains (more when GPU_MAX_HW_QUEUES allows), folded before it returns, and a fused display is made
-    // from the folded sums.  The partition depends only on the call's arguments: reproducible, and equal to
-    // the single launch up to float summation order.
-    // (Three chains at 4 samples per launch already beat one serial launch: 9.6 against 5.9 Gsamples/s.)
-    // A burst of its own wants about four launches per chain to amortise its tail (8..32 samples each).
-    uint32_t chunk = 32u;
-    if (!pipelined) { chunk = (sample_count + 11u) / 12u; chunk = chunk < 8u ? 8u : (chunk > 32u ? 32u : chunk); }
-    if (ctx->knob_chunk >= 0) chunk = (uint32_t)ctx->knob_chunk;
-    const uint32_t cut_from = pipelined ? chunk + chunk / 2u + 1u : 12u;
-    if (can_overlap && chunk > 0 && sample_count >= cut_from && (uint64_t)ctx->width * ctx->height <= (1ull << 22)) {
-        uint32_t parts = (sample_count + chunk - 1u) / chunk;
-        if (!pipelined && parts < 3u) parts = 3u;  // one launch per chain at least
-        const uint32_t user_flight = ctx->flight;
-        PtRenderParams sub = *prm;
-        if (!pipelined) {
-            ctx->flight = ctx->burst_chains;  // 3 with HIP's default 4 hardware queues (more chains would share a queue)
-            sub.fused_rgba8 = 0;
-        }
-        uint32_t begin = sample_begin, left = sample_count;
-        int rc = PT_OK;
-        for (uint32_t k = 0; k < parts && rc == PT_OK; ++k) {
-            const uint32_t n = (left + (parts - k) - 1u) / (parts - k);  // as equal as integers allow
-            rc = pt_render(ctx, begin, n, &sub);
-            begin += n; left -= n;
-        }
-        if (!pipelined) {
-            const int rj = join_chains(ctx);
-            ctx->flight = user_flight;
-            if (rc == PT_OK) rc = rj;
-            if (rc == PT_OK && prm->fused_rgba8) rc = pt_resolve(ctx, PT_RESOLVE_RGBA8_CUDA);
-        }
-        return rc;
-    }
-    uint32_t chain = 0;
-    hipStream_t stream = ctx->stream;
-    if (pipelined) {
-        if (ctx->burst == 0) {
-            if (int rc = prepare_chains(ctx)) return rc;
-            HIP_TRY(hipEventRecord(ctx->fork_event, ctx->stream));
-        }
-        chain = ctx->burst % ctx->flight;
-        stream = ctx->chain_stream[chain];
-        if (ctx->burst < ctx->flight) HIP_TRY(hipStreamWaitEvent(stream, ctx->fork_event, 0));  // first launch of this chain in the burst
-    } else {
-        if (int rc = join_chains(ctx)) return rc;
-    }
-    PathArgs a{};
-    a.accum = chain == 0 ? ctx->accum : ctx->chain_acc[chain];
-    // a launch that overlaps others displays in a pass of its own behind it (pt_display_kernel): the mean over all chains
-    const bool display_pass = pipelined && prm->fused_rgba8;
-    a.rgba = (prm->fused_rgba8 && !display_pass) ? (uint32_t*)ctx->display : nullptr;
-    a.counters = (prm->flags & PT_FLAG_COUNTERS) ? ctx->counters : nullptr;
-    a.s0 = sample_begin; a.count = sample_count;
-    a.max_depth = prm->max_depth; a.rr_depth = prm->rr_depth; a.seed_hash = hash32(prm->seed);
-    a.light_colour = (prm->flags & PT_FLAG_LIGHT_COLOUR) ? 1u : 0u;
-    a.acc_mode = prm->acc_mode;
-    a.mean_t = 1.0f / (float)(sample_begin + 1u);  // :299
-    a.tiles_x = (ctx->width + 7u) / 8u; a.tiles_y = (ctx->height + 7u) / 8u;
-    a.num_tiles = a.tiles_x * a.tiles_y;
-    const bool nee = (prm->flags & PT_FLAG_NEE_MIS) != 0, cnt = (prm->flags & PT_FLAG_COUNTERS) != 0;
-    uint32_t& resident = ctx->resident_blocks[(nee ? 2 : 0) + (cnt ? 1 : 0)];
-    if (resident == 0) HIP_TRY(pt_path_resident_blocks(nee, cnt, ctx->device, &resident));
-    a.inv_tiles_x = 1.0f / (float)a.tiles_x;
-    a.total_w = (float)(sample_begin + sample_count); a.inv_total_w = 1.0f / a.total_w;
-    // Grid: no more waves than are resident at once.  Overlapping launches fill the chip together, so each
-    // can be smaller: fewer waves means more pixels per lane (lanes that regenerate instead of idling until
-    // the launch ends).  The chains' grids together are ~1.35x the resident capacity; a launch with enough
-    // work to keep its lanes regenerating for long (>= 14 samples per lane) gets as many waves as that allows.
-    // (measured at 720p, 1 spp, Gsamples/s: 4 x 518 blocks 8.5, 6 x 345 9.3, 8 x 259 9.5, 8 x 514 8.6;
-    //  4K, 16 spp: 8 x 1536 11.0, 8 x 400 8.6)
-    // (Long launches on more chains than the ~4 the command processor keeps active at once underfill the chip
-    //  with small grids: `random4096` at 720p, 8 x 259 blocks 168 Msamples/s, 4 x 518 226.  A sample of a
-    //  large scene therefore counts as many: its brute-force cost relative to the Cornell box's.)
-    const DevSceneF& f = ctx->sf;
-    const uint32_t serial_cost = 25u * (uint32_t)f.ns + 7u * (uint32_t)(f.nax + f.nay + f.naz) + 13u * (uint32_t)f.npg + 35u * (uint32_t)f.nt;
-    uint32_t cap = resident;
-    if (pipelined) {
-        const uint64_t weight = serial_cost > 400u ? serial_cost / 400u : 1u;
-        const uint64_t by_work = ((uint64_t)ctx->width * ctx->height * sample_count * weight) / (256u * 14u);
-        const uint32_t by_fill = (resident * 27u) / (20u * ctx->flight);
-        const uint32_t want = by_work > by_fill ? (by_work > resident ? resident : (uint32_t)by_work) : by_fill;
-        if (want < cap) cap = want;
-    }
-    // work unit = 4x4 pixels; a ticket is at least units_per_grab of them.  Default: aim at >= 8
-    // tickets per wave of the grid, but never more than one 8x8 tile per ticket.
-    const uint32_t units = a.num_tiles * 4u;
-    uint32_t upg;
-    if (prm->pixels_per_wave) upg = (prm->pixels_per_wave + 15u) / 16u;
-    else { upg = units / (cap * 4u * 8u); upg = upg > 4u ? 4u : upg; }
-    a.units_per_grab = upg < 1u ? 1u : (upg > 65536u ? 65536u : upg);
-    uint32_t blocks = (units / a.units_per_grab + 3u) / 4u;  // no more waves than tickets ...
-    if (blocks > cap) blocks = cap;                          // ... and no more than the cap
-    {   // lane-parallel intersection pays while (rays in flight) x (per-ray cost) < cost of one 64-ray pass
-        const uint32_t serial = serial_cost;
-        const uint32_t per_ray = 40u + 27u * (((uint32_t)f.ns + 63u) / 64u) + 15u * (((uint32_t)f.np + 63u) / 64u) + 37u * (((uint32_t)f.nt + 63u) / 64u);
-        uint32_t few = serial / per_ray;
-        a.few_max = few > 48u ? 48u : few;
-        if (ctx->knob_few_max >= 0) a.few_max = (uint32_t)ctx->knob_few_max;
-    }
-    if (ctx->knob_max_blocks > 0 && blocks > (uint32_t)ctx->knob_max_blocks) blocks = (uint32_t)ctx->knob_max_blocks;
-    if (blocks < 8u) blocks = 8u;                            // every shard needs a block to serve its tiles
-    // launches of one chain are ordered on its stream (chain 0 also serves unpipelined launches, which
-    // join_chains() orders after it): each zeroes the set its successor on the same chain will use
-    a.work_counter = ctx->work_counter + WORK_SET_WORDS * (2u * chain + ctx->work_parity[chain]);
-    a.next_counter = ctx->work_counter + WORK_SET_WORDS * (2u * chain + (ctx->work_parity[chain] ^ 1u));
-    const char* trace_file = ctx->knob_trace.empty() ? nullptr : ctx->knob_trace.c_str();  // kernel-timeline experiments (tools/gpu_trace.py)
-    if (trace_file) {
-        const size_t waves = (size_t)blocks * 4u;
-        if (ctx->trace_waves < waves) {
-            if (ctx->trace) HIP_TRY(hipFree(ctx->trace));
-            HIP_TRY(hipMalloc((void**)&ctx->trace, waves * 128));
-            ctx->trace_waves = waves;
-        }
-        HIP_TRY(hipMemsetAsync(ctx->trace, 0, waves * 128, stream));
-        a.trace = ctx->trace;
-    } else a.trace = nullptr;
-    HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, blocks, stream));
-    if (display_pass) ctx->burst_displayed = true;
-    if (display_pass)
-        HIP_TRY(pt_launch_display(chain_accs(ctx, ctx->flight), (uint32_t*)ctx->display, ctx->width * ctx->height, stream));
-    if (pipelined) {
-        HIP_TRY(hipEventRecord(ctx->chain_done[chain], stream));
-        ctx->burst++;
-    }
-    if (trace_file) {
-        std::vector<uint64_t> host((size_t)blocks * 4u * 16u);
-        HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipMemcpy(host.data(), ctx->trace, host.size() * 8, hipMemcpyDeviceToHost));
-        if (FILE* f = fopen(trace_file, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
-    }
-    ctx->work_parity[chain] ^= 1u;
-    ctx->last_acc_mode = prm->acc_mode;
-    if (prm->fused_rgba8) ctx->display_bytes = (size_t)ctx->width * ctx->height * 4;
-    return PT_OK;
+    if (wants_parts(ctx, sample_count, prm)) return render_in_parts(ctx, sample_begin, sample_count, prm);
+    return launch_path(ctx, sample_begin, sample_count, prm);
 }
 
 int pt_resolve(PtContext* ctx, uint32_t mode) {
