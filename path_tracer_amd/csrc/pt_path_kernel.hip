@@ -527,15 +527,18 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
             closest_hit<COUNT>(sc, o, d, t_hit, id_hit, c_roots);
         }
         PT_SECTION(_isect)
-        if (alive) {
+        {
+            // (miss and hit are two regions side by side, not an if/else inside `if (alive)`: one nesting
+            //  level fewer for hipcc to copy the lane state around)
             const float t = t_hit; const int id = id_hit;
-            if (COUNT) { c_rays++; if (id >= 0) c_hits++; }
+            if (COUNT) { if (alive) { c_rays++; if (id >= 0) c_hits++; } }
             bool end_path = false;
-            if (id < 0) {
+            if (alive && id < 0) {
                 // miss: black background (:208); an escaping shadow ray reached no light
                 if (NEE && shadow) { shadow = false; if (cont) { o = pend_o; d = pend_d; } else end_path = true; }
                 else end_path = true;
-            } else {
+            }
+            if (alive && id >= 0) {
                 // ---- (5) hit record of the winner (:66-71, :95-100, :142-147; Intersection.cuh:29-32):
                 //          three independent 16-B gathers from one 64-B line
                 const float4 g0 = sc.rec[4 * id], g1 = sc.rec[4 * id + 1], g2 = sc.rec[4 * id + 2];
