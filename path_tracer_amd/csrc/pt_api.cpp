@@ -83,6 +83,7 @@ struct PtContext {
     size_t chain_acc_pixels = 0;
     uint32_t burst = 0;                // launches since the chains were last joined
     bool burst_displayed = false;      // some launch of the burst made a display pass
+    uint32_t compute_units = 256;
     uint32_t burst_chains = 3;         // chains of a burst that pt_render opens by itself: GPU_MAX_HW_QUEUES - 4, 3..8
     uint64_t* trace = nullptr;         // PT_AMD_TRACE=<file>: per-wave timeline of the last launch (PT_TRACE kernel builds)
     size_t trace_waves = 0;
@@ -328,7 +329,9 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
     if (pipelined) {
         const uint64_t weight = serial_cost > 400u ? serial_cost / 400u : 1u;
         const uint64_t by_work = ((uint64_t)ctx->width * ctx->height * sample_count * weight) / (256u * 14u);
-        const uint32_t by_fill = (resident * 27u) / (20u * ctx->flight);
+        // (the factor is against 6 waves/SIMD: a build that fits 7 has the same optimum in blocks)
+        const uint32_t six = ctx->compute_units * 6u;
+        const uint32_t by_fill = ((resident < six ? resident : six) * 27u) / (20u * ctx->flight);
         const uint32_t want = by_work > by_fill ? (by_work > resident ? resident : (uint32_t)by_work) : by_fill;
         if (want < cap) cap = want;
     }
@@ -402,6 +405,11 @@ int pt_create(int device_id, PtContext** out) {
     PtContext* ctx = new (std::nothrow) PtContext();
     if (!ctx) return fail(PT_ERR_INVALID, "out of host memory");
     ctx->device = device_id;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->compute_units = (uint32_t)prop.multiProcessorCount;
+    }
     if (const char* e = getenv("PT_AMD_FEW_MAX")) ctx->knob_few_max = atoi(e);
     if (const char* e = getenv("PT_AMD_MAX_BLOCKS")) ctx->knob_max_blocks = atoi(e);
     if (const char* e = getenv("PT_AMD_TRACE")) ctx->knob_trace = e;

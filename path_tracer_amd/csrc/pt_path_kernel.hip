@@ -327,11 +327,11 @@ __device__ __forceinline__ const PT_CONST KArgs* cold() {
     return k;
 }
 
-// Register budget.  The light-sampling build needs 102 VGPRs when left alone (4 waves/SIMD); asked for 5
-// waves/SIMD it fits 96 with two spilled registers and runs 8 % faster.  The plain build sits at 77 VGPRs
-// (6 waves/SIMD) and is left unconstrained: forcing 7 or 8 waves/SIMD spills and costs 6-27 %.
+// Register budget.  The light-sampling build needs 85 VGPRs when left alone (5 waves/SIMD); asked for 6
+// waves/SIMD it fits 80 with two spilled registers and runs 5 % faster.  The plain build sits at 71 VGPRs
+// (7 waves/SIMD) and is left unconstrained.
 #ifndef PT_NEE_WAVES
-#define PT_NEE_WAVES 5
+#define PT_NEE_WAVES 6
 #endif
 #define PT_WAVES_PER_EU ((NEE && !COUNT) ? PT_NEE_WAVES : 1)
 // Threads per workgroup of the path kernel.  One wave per workgroup: the waves of a launch share nothing
@@ -394,125 +394,12 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
 #define PT_SECTION(acc)
 #endif
 
+    // Loop order: trace + shade first, regeneration last (the first trip finds no lane alive and goes
+    // straight to the regeneration steps).  With regeneration first hipcc kept the lane state in two
+    // register sets and copied one to the other on every trip (~45 v_mov, 78 VGPRs; the light-sampling
+    // build 96 VGPRs with spills); in this order it needs 71 and 85 and 40-120 fewer instructions.
     for (;;) {
-        // Steps (1)-(3) run at the few lanes whose path just ended; executed on every trip they
-        // cost as many instructions as a third of an intersection at ~15 % lane occupancy.  They
-        // are therefore entered only when PT_REGEN_MIN lanes have something to do there (or no
-        // lane is tracing), which trades a few idle lane-trips for fewer low-occupancy instructions.
-        const bool todo = !alive && (my >= 0 || !exhausted);
-        const uint64_t todo_mask = __ballot(todo);
-        const bool regen = (uint32_t)__popcll(todo_mask) >= PT_REGEN_MIN || __ballot(alive) == 0ull;
-        if (regen) {
-        const PT_CONST KArgs* kc = cold();
-        // ---- (1) finished pixels are flushed: one 16-B store (the 16-B load was issued when the
-        //          pixel was taken, so its latency is long gone)
-        if (!alive && my >= 0 && sample_i == a.count) {
-            float4 acc;
-            if (a.acc_mode == 0u) {  // PT_ACC_SUM
-                acc = make_float4(prev.x + sum.x, prev.y + sum.y, prev.z + sum.z, prev.w + (float)a.count);
-            } else {  // PT_ACC_RUNNING_MEAN, renderKernel :297-304 (count == 1, s0 = frame_count)
-                acc = make_float4(sum.x, sum.y, sum.z, 1.0f);
-                if (a.s0 > 0u) {
-                    const float t = kc->a.mean_t;
-                    acc.x = sum.x * t + prev.x * (1.0f - t);
-                    acc.y = sum.y * t + prev.y * (1.0f - t);
-                    acc.z = sum.z * t + prev.z * (1.0f - t);
-                }
-            }
-            a.accum[pixel] = acc;
-            uint32_t* const rgba = kc->a.rgba;
-            if (rgba) {  // fused convertToRGBAKernel (launches that overlap others display in a pass of their own)
-                // every pixel normally holds the same count: its reciprocal comes from the host (same IEEE divide)
-                const float inv = (a.acc_mode != 0u) ? 1.0f : (acc.w == kc->a.total_w ? kc->a.inv_total_w : 1.0f / acc.w);
-                rgba[pixel] = pack_rgba8_cuda(acc.x * inv, acc.y * inv, acc.z * inv);
-            }
-            my = -1;
-        }
-        // ---- (2) lanes without a pixel pull the next one from the wave's pool; an empty pool is
-        //          refilled with one ticket from the global counter
-        const bool want = !alive && my < 0;
-        const uint64_t want_mask = __ballot(want);
-        if (want_mask != 0ull && !exhausted) {
-            if (pool_next >= pool_size) {
-                const uint32_t need = max(a.units_per_grab, ((uint32_t)__popcll(want_mask) + 15u) >> 4);
-                uint32_t ticket = 0;
-                if (lane == 0) ticket = atomicAdd(a.work_counter + shard * 32u, need);
-                ticket = __builtin_amdgcn_readfirstlane(ticket);
-                if (ticket >= shard_units) {
-                    exhausted = true;
-#ifdef PT_TRACE
-                    tr_exh = wall_clock64();
-#endif
-                } else {
-                    unit0 = ticket;
-                    pool_size = min(need, shard_units - ticket) * 16u;
-                    pool_next = 0;
-                }
-            }
-            if (!exhausted) {
-                const uint32_t cand = pool_next + lane_prefix(want_mask);
-                if (want && cand < pool_size) {
-                    const uint32_t unit = unit0 + (cand >> 4), li = cand & 15u, q = unit & 3u;
-                    const uint32_t tile = (unit >> 2) * 8u + shard;
-                    // tile / tiles_x without the 25-instruction integer division: float quotient + one fix-up
-                    uint32_t ty = (uint32_t)(((float)tile + 0.5f) * a.inv_tiles_x);
-                    int tx = (int)(tile - ty * a.tiles_x);
-                    if (tx < 0) { tx += (int)a.tiles_x; ty--; }
-                    if (tx >= (int)a.tiles_x) { tx -= (int)a.tiles_x; ty++; }
-                    px = (uint32_t)tx * 8u + (q & 1u) * 4u + (li & 3u);
-                    py = ty * 8u + (q >> 1) * 4u + (li >> 2);
-                    if (px < a.width && py < a.height) {
-                        my = (int)cand;
-                        pixel = py * a.width + px;
-                        pixkey = pt_hash(a.seed_hash + pixel);
-                        if (need_prev) prev = a.accum[pixel];
-                        sample_i = 0;
-                        sum = v3(0, 0, 0);
-                    }
-                }
-                pool_next = min(pool_next + (uint32_t)__popcll(want_mask), pool_size);
-            }
-        }
-        // ---- (3) start the next sample of the owned pixel
-        if (!alive && my >= 0 && sample_i < a.count) {
-            key = pt_hash(pixkey + (a.s0 + sample_i));
-            sample_i++;
-            // renderKernel :286-291 + generateCameraRay :245-265:
-            //   (2*(x + xi)/W - 1) * half_w  ==  (x + xi) * (2*half_w/W) - half_w
-            const PT_CONST DevCamF& cam = kc->cam;
-            const float xo = ((float)px + uni(pt_draw(key, 0, 0))) * cam.sx - cam.half_w;
-            const float yo = ((float)py + uni(pt_draw(key, 0, 1))) * cam.sy - cam.half_h;
-            o = v3(cam.ox, cam.oy, cam.oz);
-            d = v3(cam.fx + cam.rx * xo + cam.ux * yo, cam.fy + cam.ry * xo + cam.uy * yo, cam.fz + cam.rz * xo + cam.uz * yo);
-            const float lens_radius = cam.lens_radius;
-            if (lens_radius > 0.0f) {  // wave-uniform
-                // Depth of field, Camera_t::getRayDevice (Camera.cu:31-47): the virtual screen is at focus_dist
-                // (Camera.cu:15-19), the origin moves on the lens disk (randomInUnitDisk, :25-29) in the
-                // camera's right/up plane and the ray aims at the point the pinhole ray reaches on that screen.
-                const float r = fsqrt(uni(pt_draw(key, 0, 2))) * lens_radius;
-                const float th = uni(pt_draw(key, 0, 3));
-                const float lx = r * cos2pi(th), ly = r * sin2pi(th);
-                const V3 org = v3(o.x + cam.rx * lx + cam.ux * ly, o.y + cam.ry * lx + cam.uy * ly, o.z + cam.rz * lx + cam.uz * ly);
-                const float fd = cam.focus_dist;
-                d = v3(o.x + d.x * fd - org.x, o.y + d.y * fd - org.y, o.z + d.z * fd - org.z);
-                o = org;
-            }
-            d = normalized(d);
-            beta = v3(1, 1, 1);
-            L = v3(0, 0, 0);
-            depth = 0;
-            alive = true;
-            if (NEE) { shadow = false; prev_pdf_b = -1.0f; }
-            if (COUNT) c_samples++;
-        }
-        }  // regen
-        PT_SECTION(_regen)
-        if (__ballot(alive) == 0ull) {
-            // nothing in flight: done when no lane holds a pixel and the frame is exhausted;
-            // otherwise some lane flushes / pulls on the next trip
-            if (__ballot(my >= 0) == 0ull && exhausted) break;
-            continue;
-        }
+        if (__ballot(alive) != 0ull) {
         // ---- (4) one ray: 64 rays per instruction stream, or lane-parallel when few lanes trace
         float t_hit = T_BEST_INIT; int id_hit = -1;
         const uint64_t alive_mask = __ballot(alive);
@@ -698,6 +585,122 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
             if (end_path) { sum = sum + L; alive = false; }
         }
         PT_SECTION(_shade)
+        }
+        // Steps (1)-(3) run at the few lanes whose path just ended; executed on every trip they
+        // cost as many instructions as a third of an intersection at ~15 % lane occupancy.  They
+        // are therefore entered only when PT_REGEN_MIN lanes have something to do there (or no
+        // lane is tracing), which trades a few idle lane-trips for fewer low-occupancy instructions.
+        const bool todo = !alive && (my >= 0 || !exhausted);
+        const uint64_t todo_mask = __ballot(todo);
+        const bool regen = (uint32_t)__popcll(todo_mask) >= PT_REGEN_MIN || __ballot(alive) == 0ull;
+        if (regen) {
+        const PT_CONST KArgs* kc = cold();
+        // ---- (1) finished pixels are flushed: one 16-B store (the 16-B load was issued when the
+        //          pixel was taken, so its latency is long gone)
+        if (!alive && my >= 0 && sample_i == a.count) {
+            float4 acc;
+            if (a.acc_mode == 0u) {  // PT_ACC_SUM
+                acc = make_float4(prev.x + sum.x, prev.y + sum.y, prev.z + sum.z, prev.w + (float)a.count);
+            } else {  // PT_ACC_RUNNING_MEAN, renderKernel :297-304 (count == 1, s0 = frame_count)
+                acc = make_float4(sum.x, sum.y, sum.z, 1.0f);
+                if (a.s0 > 0u) {
+                    const float t = kc->a.mean_t;
+                    acc.x = sum.x * t + prev.x * (1.0f - t);
+                    acc.y = sum.y * t + prev.y * (1.0f - t);
+                    acc.z = sum.z * t + prev.z * (1.0f - t);
+                }
+            }
+            a.accum[pixel] = acc;
+            uint32_t* const rgba = kc->a.rgba;
+            if (rgba) {  // fused convertToRGBAKernel (launches that overlap others display in a pass of their own)
+                // every pixel normally holds the same count: its reciprocal comes from the host (same IEEE divide)
+                const float inv = (a.acc_mode != 0u) ? 1.0f : (acc.w == kc->a.total_w ? kc->a.inv_total_w : 1.0f / acc.w);
+                rgba[pixel] = pack_rgba8_cuda(acc.x * inv, acc.y * inv, acc.z * inv);
+            }
+            my = -1;
+        }
+        // ---- (2) lanes without a pixel pull the next one from the wave's pool; an empty pool is
+        //          refilled with one ticket from the global counter
+        const bool want = !alive && my < 0;
+        const uint64_t want_mask = __ballot(want);
+        if (want_mask != 0ull && !exhausted) {
+            if (pool_next >= pool_size) {
+                const uint32_t need = max(a.units_per_grab, ((uint32_t)__popcll(want_mask) + 15u) >> 4);
+                uint32_t ticket = 0;
+                if (lane == 0) ticket = atomicAdd(a.work_counter + shard * 32u, need);
+                ticket = __builtin_amdgcn_readfirstlane(ticket);
+                if (ticket >= shard_units) {
+                    exhausted = true;
+#ifdef PT_TRACE
+                    tr_exh = wall_clock64();
+#endif
+                } else {
+                    unit0 = ticket;
+                    pool_size = min(need, shard_units - ticket) * 16u;
+                    pool_next = 0;
+                }
+            }
+            if (!exhausted) {
+                const uint32_t cand = pool_next + lane_prefix(want_mask);
+                if (want && cand < pool_size) {
+                    const uint32_t unit = unit0 + (cand >> 4), li = cand & 15u, q = unit & 3u;
+                    const uint32_t tile = (unit >> 2) * 8u + shard;
+                    // tile / tiles_x without the 25-instruction integer division: float quotient + one fix-up
+                    uint32_t ty = (uint32_t)(((float)tile + 0.5f) * a.inv_tiles_x);
+                    int tx = (int)(tile - ty * a.tiles_x);
+                    if (tx < 0) { tx += (int)a.tiles_x; ty--; }
+                    if (tx >= (int)a.tiles_x) { tx -= (int)a.tiles_x; ty++; }
+                    px = (uint32_t)tx * 8u + (q & 1u) * 4u + (li & 3u);
+                    py = ty * 8u + (q >> 1) * 4u + (li >> 2);
+                    if (px < a.width && py < a.height) {
+                        my = (int)cand;
+                        pixel = py * a.width + px;
+                        pixkey = pt_hash(a.seed_hash + pixel);
+                        if (need_prev) prev = a.accum[pixel];
+                        sample_i = 0;
+                        sum = v3(0, 0, 0);
+                    }
+                }
+                pool_next = min(pool_next + (uint32_t)__popcll(want_mask), pool_size);
+            }
+        }
+        // ---- (3) start the next sample of the owned pixel
+        if (!alive && my >= 0 && sample_i < a.count) {
+            key = pt_hash(pixkey + (a.s0 + sample_i));
+            sample_i++;
+            // renderKernel :286-291 + generateCameraRay :245-265:
+            //   (2*(x + xi)/W - 1) * half_w  ==  (x + xi) * (2*half_w/W) - half_w
+            const PT_CONST DevCamF& cam = kc->cam;
+            const float xo = ((float)px + uni(pt_draw(key, 0, 0))) * cam.sx - cam.half_w;
+            const float yo = ((float)py + uni(pt_draw(key, 0, 1))) * cam.sy - cam.half_h;
+            o = v3(cam.ox, cam.oy, cam.oz);
+            d = v3(cam.fx + cam.rx * xo + cam.ux * yo, cam.fy + cam.ry * xo + cam.uy * yo, cam.fz + cam.rz * xo + cam.uz * yo);
+            const float lens_radius = cam.lens_radius;
+            if (lens_radius > 0.0f) {  // wave-uniform
+                // Depth of field, Camera_t::getRayDevice (Camera.cu:31-47): the virtual screen is at focus_dist
+                // (Camera.cu:15-19), the origin moves on the lens disk (randomInUnitDisk, :25-29) in the
+                // camera's right/up plane and the ray aims at the point the pinhole ray reaches on that screen.
+                const float r = fsqrt(uni(pt_draw(key, 0, 2))) * lens_radius;
+                const float th = uni(pt_draw(key, 0, 3));
+                const float lx = r * cos2pi(th), ly = r * sin2pi(th);
+                const V3 org = v3(o.x + cam.rx * lx + cam.ux * ly, o.y + cam.ry * lx + cam.uy * ly, o.z + cam.rz * lx + cam.uz * ly);
+                const float fd = cam.focus_dist;
+                d = v3(o.x + d.x * fd - org.x, o.y + d.y * fd - org.y, o.z + d.z * fd - org.z);
+                o = org;
+            }
+            d = normalized(d);
+            beta = v3(1, 1, 1);
+            L = v3(0, 0, 0);
+            depth = 0;
+            alive = true;
+            if (NEE) { shadow = false; prev_pdf_b = -1.0f; }
+            if (COUNT) c_samples++;
+        }
+        }  // regen
+        PT_SECTION(_regen)
+        // nothing in flight: done when no lane holds a pixel and the frame is exhausted; otherwise
+        // some lane flushes / pulls on the next trip
+        if (__ballot(alive) == 0ull && __ballot(my >= 0) == 0ull && exhausted) break;
     }
 
 #ifdef PT_TRACE
