@@ -89,8 +89,8 @@ struct PtContext {
     size_t trace_waves = 0;
     uint32_t resident_blocks[4] = {0, 0, 0, 0};  // per kernel variant (nee, count)
     // tuning / tracing knobs for tools/gpu_ab.py and tools/gpu_trace.py, read once at pt_create
-    // (PT_AMD_FEW_MAX, PT_AMD_MAX_BLOCKS, PT_AMD_CHUNK, PT_AMD_TRACE); -1 / empty = not set
-    int knob_few_max = -1, knob_max_blocks = -1, knob_chunk = -1;
+    // (PT_AMD_FEW_MAX, PT_AMD_MAX_BLOCKS, PT_AMD_CHUNK, PT_AMD_REGEN_MIN, PT_AMD_TRACE); -1 / empty = not set
+    int knob_few_max = -1, knob_max_blocks = -1, knob_chunk = -1, knob_regen_min = -1;
     std::string knob_trace;
 };
 
@@ -351,6 +351,13 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
         a.few_max = few > 48u ? 48u : few;
         if (ctx->knob_few_max >= 0) a.few_max = (uint32_t)ctx->knob_few_max;
     }
+    // One-sample launches: every path end costs a flush, a pull and a camera ray (~150 instructions at a few
+    // lanes), so those steps wait for 12 lanes (+2 %, serial +5 %) -- unless a trip of waiting costs more than
+    // that (large scenes: 12 lanes idle through a 4096-sphere loop lose 6 %).
+    a.regen_min = 1u;
+    if (sample_count == 1u) { const uint32_t r = 4800u / (serial_cost ? serial_cost : 1u); a.regen_min = r > 12u ? 12u : r; }
+    if (ctx->knob_regen_min >= 0) a.regen_min = (uint32_t)ctx->knob_regen_min;
+    if (a.regen_min < 1u) a.regen_min = 1u;
     if (ctx->knob_max_blocks > 0 && blocks > (uint32_t)ctx->knob_max_blocks) blocks = (uint32_t)ctx->knob_max_blocks;
     if (blocks < 8u) blocks = 8u;                            // every shard needs a block to serve its tiles
     // launches of one chain are ordered on its stream (chain 0 also serves unpipelined launches, which
@@ -414,6 +421,7 @@ int pt_create(int device_id, PtContext** out) {
     if (const char* e = getenv("PT_AMD_MAX_BLOCKS")) ctx->knob_max_blocks = atoi(e);
     if (const char* e = getenv("PT_AMD_TRACE")) ctx->knob_trace = e;
     if (const char* e = getenv("PT_AMD_CHUNK")) ctx->knob_chunk = atoi(e);
+    if (const char* e = getenv("PT_AMD_REGEN_MIN")) ctx->knob_regen_min = atoi(e);
     if (const char* e = getenv("GPU_MAX_HW_QUEUES")) {  // HIP reads the same variable when it initialises
         const int q = atoi(e) - 4;
         ctx->burst_chains = q < 3 ? 3u : (q > (int)PT_MAX_CHAINS ? PT_MAX_CHAINS : (uint32_t)q);

@@ -25,11 +25,9 @@
 
 #include <float.h>
 
-// Lanes that must have ended their path before the regeneration steps are entered.  Measured on
-// the MI355X (profiles/r1_variants2.json): 1 (every trip) is fastest; 8/16/24/32 lose 1-12 %.
-#ifndef PT_REGEN_MIN
-#define PT_REGEN_MIN 1u
-#endif
+// (The number of lanes that must have ended their path before the regeneration steps are entered is a
+// launch argument, PathArgs::regen_min: 12 for one-sample launches, where every path end costs a flush, a
+// pull and a camera ray, +2 %; 1 otherwise, where larger values lose 1-3 %.)
 
 namespace {
 
@@ -588,11 +586,11 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
         }
         // Steps (1)-(3) run at the few lanes whose path just ended; executed on every trip they
         // cost as many instructions as a third of an intersection at ~15 % lane occupancy.  They
-        // are therefore entered only when PT_REGEN_MIN lanes have something to do there (or no
+        // are therefore entered only when a.regen_min lanes have something to do there (or no
         // lane is tracing), which trades a few idle lane-trips for fewer low-occupancy instructions.
         const bool todo = !alive && (my >= 0 || !exhausted);
         const uint64_t todo_mask = __ballot(todo);
-        const bool regen = (uint32_t)__popcll(todo_mask) >= PT_REGEN_MIN || __ballot(alive) == 0ull;
+        const bool regen = (uint32_t)__popcll(todo_mask) >= a.regen_min || __ballot(alive) == 0ull;
         if (regen) {
         const PT_CONST KArgs* kc = cold();
         // ---- (1) finished pixels are flushed: one 16-B store (the 16-B load was issued when the

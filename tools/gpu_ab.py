@@ -40,6 +40,7 @@ for v in sys.argv[1:]:
         if kv.startswith("blocks="): env["PT_AMD_MAX_BLOCKS"] = kv.split("=")[1]
         elif kv.startswith("flight="): env["PT_FLIGHT"] = kv.split("=")[1]
         elif kv.startswith("few="): env["PT_AMD_FEW_MAX"] = kv.split("=")[1]
+        elif kv.startswith("regen="): env["PT_AMD_REGEN_MIN"] = kv.split("=")[1]
         elif kv.startswith("queues="): env["GPU_MAX_HW_QUEUES"] = kv.split("=")[1]
         elif kv != "main": env["PT_AMD_LIB"] = os.path.join(ROOT, "path_tracer_amd", "lib", f"libpt_amd_{kv}.so")
     p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=280)
