@@ -336,11 +336,13 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
         if (want < cap) cap = want;
     }
     // work unit = 4x4 pixels; a ticket is at least units_per_grab of them.  Default: aim at >= 8
-    // tickets per wave of the grid, but never more than one 8x8 tile per ticket.
+    // tickets per wave of the grid, but never more than one 8x8 tile per ticket -- two for launches of one
+    // or two samples, where the atomics count (720p, 1 spp, 8 chains: 64 pixels per ticket 10.0, 128-256
+    // 10.15, 384 and more 9.96 Gsamples/s; 4K, 16 spp: 64 pixels 11.73, 128 11.63).
     const uint32_t units = a.num_tiles * 4u;
     uint32_t upg;
     if (prm->pixels_per_wave) upg = (prm->pixels_per_wave + 15u) / 16u;
-    else { upg = units / (cap * 4u * 8u); upg = upg > 4u ? 4u : upg; }
+    else { const uint32_t most = sample_count <= 2u ? 8u : 4u; upg = units / (cap * 4u * 8u); upg = upg > most ? most : upg; }
     a.units_per_grab = upg < 1u ? 1u : (upg > 65536u ? 65536u : upg);
     uint32_t blocks = (units / a.units_per_grab + 3u) / 4u;  // no more waves than tickets ...
     if (blocks > cap) blocks = cap;                          // ... and no more than the cap

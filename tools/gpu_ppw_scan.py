@@ -1,15 +1,15 @@
 """720p, 1 spp per frame, fused display: Msamples/s against pixels per ticket and frames in flight."""
 import os, sys, time
-os.environ["GPU_MAX_HW_QUEUES"] = "8"
+os.environ["GPU_MAX_HW_QUEUES"] = "16"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from path_tracer_amd import abi, scenes
 from path_tracer_amd.renderer import Renderer
 r = Renderer(0)
 sc, cam = scenes.cuda_default(1280, 720)
 r.set_scene(sc); r.set_camera(cam)
-for flight in (4, 3):
+for flight in (8, 4):
     r.set_frames_in_flight(flight)
-    for ppw in (0, 64, 128, 192, 256, 384, 512, 1024):
+    for ppw in (0, 64, 96, 128, 192, 256, 320, 384, 512):
         p = abi.render_params(fused_rgba8=1, pixels_per_wave=ppw)
         r.reset()
         best = 0
