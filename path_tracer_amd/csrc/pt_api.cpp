@@ -87,7 +87,7 @@ struct PtContext {
     uint32_t burst_chains = 3;         // chains of a burst that pt_render opens by itself: GPU_MAX_HW_QUEUES - 4, 3..8
     uint64_t* trace = nullptr;         // PT_AMD_TRACE=<file>: per-wave timeline of the last launch (PT_TRACE kernel builds)
     size_t trace_waves = 0;
-    uint32_t resident_blocks[4] = {0, 0, 0, 0};  // per kernel variant (nee, count)
+    uint32_t resident_blocks[8] = {};  // per kernel build (nee, count, few)
     // tuning / tracing knobs for tools/gpu_ab.py and tools/gpu_trace.py, read once at pt_create
     // (PT_AMD_FEW_MAX, PT_AMD_MAX_BLOCKS, PT_AMD_CHUNK, PT_AMD_REGEN_MIN, PT_AMD_TRACE); -1 / empty = not set
     int knob_few_max = -1, knob_max_blocks = -1, knob_chunk = -1, knob_regen_min = -1;
@@ -310,8 +310,23 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
     a.tiles_x = (ctx->width + 7u) / 8u; a.tiles_y = (ctx->height + 7u) / 8u;
     a.num_tiles = a.tiles_x * a.tiles_y;
     const bool nee = (prm->flags & PT_FLAG_NEE_MIS) != 0, cnt = (prm->flags & PT_FLAG_COUNTERS) != 0;
-    uint32_t& resident = ctx->resident_blocks[(nee ? 2 : 0) + (cnt ? 1 : 0)];
-    if (resident == 0) HIP_TRY(pt_path_resident_blocks(nee, cnt, ctx->device, &resident));
+    // Lane-parallel intersection for waves with few rays pays while (rays in flight) x (per-ray cost) < cost of
+    // one 64-ray pass.  The kernel build that contains it costs the common loop 2-3 %, so it is used where
+    // waves drain alone (short launches that do not overlap others) or the scene is large (threshold >= 6 rays).
+    const DevSceneF& f = ctx->sf;
+    const uint32_t serial_cost = 25u * (uint32_t)f.ns + 7u * (uint32_t)(f.nax + f.nay + f.naz) + 13u * (uint32_t)f.npg + 35u * (uint32_t)f.nt;
+    {
+        const uint32_t per_ray = 40u + 27u * (((uint32_t)f.ns + 63u) / 64u) + 15u * (((uint32_t)f.np + 63u) / 64u) + 37u * (((uint32_t)f.nt + 63u) / 64u);
+        const uint32_t few = serial_cost / per_ray;
+        a.few_max = few > 48u ? 48u : few;
+        // (serial launches: 720p, 1 spp +15 % with it; 4K, 16 spp, 340 samples per resident lane, -3 %)
+        const uint64_t per_lane = ((uint64_t)ctx->width * ctx->height * sample_count) / ((uint64_t)ctx->compute_units * 6u * 256u);
+        if ((pipelined || per_lane >= 100u) && a.few_max < 6u) a.few_max = 0u;
+        if (ctx->knob_few_max >= 0) a.few_max = (uint32_t)ctx->knob_few_max;
+    }
+    const bool few = a.few_max > 0u;
+    uint32_t& resident = ctx->resident_blocks[(nee ? 4 : 0) + (cnt ? 2 : 0) + (few ? 1 : 0)];
+    if (resident == 0) HIP_TRY(pt_path_resident_blocks(nee, cnt, few, ctx->device, &resident));
     a.inv_tiles_x = 1.0f / (float)a.tiles_x;
     a.total_w = (float)(sample_begin + sample_count); a.inv_total_w = 1.0f / a.total_w;
     // Grid: no more waves than are resident at once.  Overlapping launches fill the chip together, so each
@@ -323,8 +338,6 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
     // (Long launches on more chains than the ~4 the command processor keeps active at once underfill the chip
     //  with small grids: `random4096` at 720p, 8 x 259 blocks 168 Msamples/s, 4 x 518 226.  A sample of a
     //  large scene therefore counts as many: its brute-force cost relative to the Cornell box's.)
-    const DevSceneF& f = ctx->sf;
-    const uint32_t serial_cost = 25u * (uint32_t)f.ns + 7u * (uint32_t)(f.nax + f.nay + f.naz) + 13u * (uint32_t)f.npg + 35u * (uint32_t)f.nt;
     uint32_t cap = resident;
     if (pipelined) {
         const uint64_t weight = serial_cost > 400u ? serial_cost / 400u : 1u;
@@ -346,13 +359,6 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
     a.units_per_grab = upg < 1u ? 1u : (upg > 65536u ? 65536u : upg);
     uint32_t blocks = (units / a.units_per_grab + 3u) / 4u;  // no more waves than tickets ...
     if (blocks > cap) blocks = cap;                          // ... and no more than the cap
-    {   // lane-parallel intersection pays while (rays in flight) x (per-ray cost) < cost of one 64-ray pass
-        const uint32_t serial = serial_cost;
-        const uint32_t per_ray = 40u + 27u * (((uint32_t)f.ns + 63u) / 64u) + 15u * (((uint32_t)f.np + 63u) / 64u) + 37u * (((uint32_t)f.nt + 63u) / 64u);
-        uint32_t few = serial / per_ray;
-        a.few_max = few > 48u ? 48u : few;
-        if (ctx->knob_few_max >= 0) a.few_max = (uint32_t)ctx->knob_few_max;
-    }
     // One-sample launches: every path end costs a flush, a pull and a camera ray (~150 instructions at a few
     // lanes), so those steps wait for 12 lanes (+2 %, serial +5 %) -- unless a trip of waiting costs more than
     // that (large scenes: 12 lanes idle through a 4096-sphere loop lose 6 %).
@@ -377,7 +383,7 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
         HIP_TRY(hipMemsetAsync(ctx->trace, 0, waves * 128, stream));
         a.trace = ctx->trace;
     } else a.trace = nullptr;
-    HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, blocks, stream));
+    HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, few, blocks, stream));
     if (display_pass) ctx->burst_displayed = true;
     if (display_pass)
         HIP_TRY(pt_launch_display(chain_accs(ctx, ctx->flight), (uint32_t*)ctx->display, ctx->width * ctx->height, stream));

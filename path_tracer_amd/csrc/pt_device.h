@@ -90,10 +90,10 @@ struct DevCamD {
 };
 
 // ---- launchers implemented in the .hip translation units ------------------------------
-hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArgs& a, bool nee, bool count,
+hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArgs& a, bool nee, bool count, bool few,
                           uint32_t blocks, hipStream_t stream);
 // Resident 256-thread blocks per CU of each path-kernel variant (occupancy query) x CU count.
-hipError_t pt_path_resident_blocks(bool nee, bool count, int device, uint32_t* blocks);
+hipError_t pt_path_resident_blocks(bool nee, bool count, bool few, int device, uint32_t* blocks);
 hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint32_t acc_mode, uint32_t mode,
                              hipStream_t stream);
 // frames in flight: the accumulators of the chains of a context ([0] = the context's own / bound buffer), by value

@@ -342,7 +342,10 @@ __device__ __forceinline__ const PT_CONST KArgs* cold() {
 #endif
 #define PT_OCC __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU)))
 
-template <bool NEE, bool COUNT>
+// FEW: the build with the lane-parallel closest hit.  Its mere presence costs the common loop 11 VGPRs and
+// 2-3 % (Cornell box, several samples per launch, overlapped launches), and it pays where waves drain alone
+// (serial launches) or where the scene is large, so the host picks the build per launch (pt_api.cpp).
+template <bool NEE, bool COUNT, bool FEW>
 __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs kargs) {
     const DevSceneF& sc = kargs.sc;
     const PathArgs& a = kargs.a;
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
     bool exhausted = false;                             // wave-uniform
     if (blockIdx.x == 0 && threadIdx.x < 8u) a.next_counter[threadIdx.x * 32u] = 0u;
     __shared__ FewLds few_lds;
-    if (threadIdx.x < 64u) {
+    if (FEW && threadIdx.x < 64u) {
         const int i = (int)threadIdx.x;
         if (i < sc.ns) few_lds.sph[i] = sc.sph[i];
         if (i < sc.np) few_lds.pla[i] = sc.pla[i];
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
         tr_in_few = (uint32_t)__popcll(alive_mask) <= a.few_max;
         if (tr_in_few) { if (!tr_few) tr_few = wall_clock64(); tr_few_trips++; tr_few_rays += (uint32_t)__popcll(alive_mask); }
 #endif
-        if ((uint32_t)__popcll(alive_mask) <= a.few_max) {  // wave-uniform: all lanes take part
+        if (FEW && (uint32_t)__popcll(alive_mask) <= a.few_max) {  // wave-uniform: all lanes take part
             closest_hit_few<COUNT>(sc, few_lds, alive_mask, (int)lane, o, d, t_hit, id_hit, c_roots);
         } else if (alive) {
             closest_hit<COUNT>(sc, o, d, t_hit, id_hit, c_roots);
@@ -826,29 +829,29 @@ __global__ __launch_bounds__(256) void pt_valu_peak_kernel(float* sink, uint32_t
 
 }  // namespace
 
-hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArgs& a, bool nee, bool count,
+namespace {
+using PathKernel = void (*)(const KArgs);
+PathKernel path_kernel(bool nee, bool count, bool few) {
+    static const PathKernel table[8] = {
+        pt_path_kernel<false, false, false>, pt_path_kernel<false, false, true>, pt_path_kernel<false, true, false>, pt_path_kernel<false, true, true>,
+        pt_path_kernel<true, false, false>,  pt_path_kernel<true, false, true>,  pt_path_kernel<true, true, false>,  pt_path_kernel<true, true, true>};
+    return table[(nee ? 4 : 0) + (count ? 2 : 0) + (few ? 1 : 0)];
+}
+}  // namespace
+
+hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArgs& a, bool nee, bool count, bool few,
                           uint32_t blocks, hipStream_t stream) {
     const dim3 grid((blocks * 256u + PT_BLOCK - 1u) / PT_BLOCK), block(PT_BLOCK);
     KArgs k;
     k.sc = sc; k.cam = cam; k.a = a;
     k.a.width = cam.width; k.a.height = cam.height;
-    if (nee) {
-        if (count) hipLaunchKernelGGL((pt_path_kernel<true, true>), grid, block, 0, stream, k);
-        else hipLaunchKernelGGL((pt_path_kernel<true, false>), grid, block, 0, stream, k);
-    } else {
-        if (count) hipLaunchKernelGGL((pt_path_kernel<false, true>), grid, block, 0, stream, k);
-        else hipLaunchKernelGGL((pt_path_kernel<false, false>), grid, block, 0, stream, k);
-    }
+    hipLaunchKernelGGL(path_kernel(nee, count, few), grid, block, 0, stream, k);
     return hipGetLastError();
 }
 
-hipError_t pt_path_resident_blocks(bool nee, bool count, int device, uint32_t* blocks) {
+hipError_t pt_path_resident_blocks(bool nee, bool count, bool few, int device, uint32_t* blocks) {
     int per_cu = 0;
-    hipError_t e;
-    if (nee) e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<true, true>, PT_BLOCK, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<true, false>, PT_BLOCK, 0);
-    else e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<false, true>, PT_BLOCK, 0)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pt_path_kernel<false, false>, PT_BLOCK, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel(nee, count, few), PT_BLOCK, 0);
     if (e != hipSuccess) return e;
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, device);

@@ -9,7 +9,7 @@ for name in ("glass", "random4096", "mis", "flight3", "flight4"):
     if os.path.exists(f): shutil.copy(f, f"profiles/{tag}_bench_{name}.json")
 # amortised time per launch from the kernel trace of the default bench run
 f = glob.glob(os.path.join(src, "trace_default", "**", "*kernel_trace.csv"), recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "pt_path_kernel<false, false>" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "pt_path_kernel<false, false" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 st = [int(r["Start_Timestamp"]) for r in rows]; en = [int(r["End_Timestamp"]) for r in rows]
 log = open(os.path.join(src, "trace_default.log")).read()

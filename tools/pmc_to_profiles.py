@@ -11,7 +11,7 @@ def counters(sub, kernel_filter):
                 agg[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
     n = max(len(disp), 1)
     return {k: v / n for k, v in agg.items()}, len(disp)
-plain = "pt_path_kernel<false, false>"
+plain = "pt_path_kernel<false, false"
 out = {"source": f"tools/profile_round.sh {tag}: rocprofv3 --pmc, one pass per counter group, bench.py --frames-in-flight 1 --steps 64 (720p, 1 spp per launch)",
        "kernel": plain, "per_launch": {}}
 for sub in ("pmc_valu", "pmc_wait", "pmc_fetch", "pmc_write"):
