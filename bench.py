@@ -126,6 +126,14 @@ def main() -> int:
             dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
+    # set-up, not a step: one launch per chain loads the kernels and allocates the chains' buffers
+    # (hipMalloc on first use), then the buffer is cleared again
+    for k in range(args.frames_in_flight):
+        r.render(k, spp, params)
+    r.flush()
+    torch.cuda.synchronize()
+    accum.zero_()
+    torch.cuda.synchronize()
     stage("set-up done")
     for s0, n in sched[:Wm]:
         r.render(s0, n, params)
