@@ -505,6 +505,33 @@ def test_large_serial_calls_are_split_over_the_chains(gpu, monkeypatch):
     assert np.all(gpu.accum()[..., 3] == 45)
 
 
+def test_kernel_builds_with_and_without_lane_parallel_mode_agree(gpu, oracle, monkeypatch):
+    """The host picks the build with or without the lane-parallel closest hit per launch (pt_api.cpp);
+    both trace the same samples: their images agree like either agrees with the oracle (the two closest-hit
+    forms round differently, so a path in a few thousand takes another branch)."""
+    from path_tracer_amd.renderer import Renderer
+    for name, size, depth in (("cuda_default", (160, 90), 50), ("random4096", (64, 36), 8)):
+        sc, cam = scenes.builtin(name, *size)
+        p = abi.render_params(max_depth=depth)
+        imgs = []
+        for few in ("0", "48"):
+            monkeypatch.setenv("PT_AMD_FEW_MAX", few)
+            r = Renderer(0)
+            try:
+                _setup(r, sc, cam)
+                for s in range(8):
+                    r.render(s, 1, p)
+                imgs.append(r.accum())
+            finally:
+                r.close()
+        monkeypatch.delenv("PT_AMD_FEW_MAX")
+        assert np.array_equal(imgs[0][..., 3], imgs[1][..., 3])
+        assert _frac_differing(_mean(imgs[0]), _mean(imgs[1])) < 0.03
+        want = oracle.render_path(sc, cam, 0, 8, p, precision=32)
+        for img in imgs:
+            assert _frac_differing(_mean(img), _mean(want)) < 0.05
+
+
 def test_frames_in_flight_random_call_sequences(gpu):
     """Any interleaving of renders with the calls that read, replace or re-target the accumulation buffer keeps
     the books: the buffer always holds exactly the samples rendered since the last reset, each once."""
