@@ -19,7 +19,7 @@ $(LIB): $(OBJS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
-build/pt_api.o: $(CSRC)/pt_api.cpp $(CSRC)/pt_device.h include/pt.h
+build/pt_api.o: $(CSRC)/pt_api.cpp $(CSRC)/pt_device.h $(CSRC)/pt_error.h include/pt.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
@@ -32,11 +32,11 @@ build/pt_f64_kernels.o: $(CSRC)/pt_f64_kernels.hip $(CSRC)/pt_device.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -ffp-contract=off -c $< -o $@
 
-build/pt_builtin_scenes.o: $(HOST)/pt_builtin_scenes.cpp include/pt_host.hpp include/pt.h
+build/pt_builtin_scenes.o: $(HOST)/pt_builtin_scenes.cpp $(CSRC)/pt_error.h include/pt_host.hpp include/pt.h
 	@mkdir -p build
 	g++ -O2 -fPIC -std=c++17 -Wall -ffp-contract=off -Iinclude -c $< -o $@
 
-build/pt_fly_camera.o: $(HOST)/pt_fly_camera.cpp include/pt.h
+build/pt_fly_camera.o: $(HOST)/pt_fly_camera.cpp $(CSRC)/pt_error.h include/pt.h
 	@mkdir -p build
 	g++ -O2 -fPIC -std=c++17 -Wall -ffp-contract=off -Iinclude -c $< -o $@
 

@@ -6,7 +6,8 @@
  * has a counterpart here.  Plain pointers and sizes only; no C++ / torch types;
  * no exception crosses the ABI.  Every entry point returns 0 on success and a
  * negative PT_ERR_* code otherwise; pt_last_error() returns a thread-local
- * human-readable message for the last failing call.
+ * human-readable message for the last failing call, and "" when the thread's
+ * last call succeeded (every entry point but pt_last_error clears it on entry).
  *
  * Citations are `path:line` under the reference tree (cuda_pathtracer/… or
  * cpu_pathtracer/…).
@@ -239,8 +240,12 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
  * redoes it from the folded sums, so a display read through the library is exact.
  * n > 3 needs more hardware queues than HIP's default of 4 per process:
  * GPU_MAX_HW_QUEUES >= n + 4 in the environment before HIP initialises (16 for
- * n = 8).  Chains that share a queue serialise: with the default, n = 4 is
- * slower than n = 3.  Memory: n - 1 more accumulation buffers.
+ * n = 8).  Chains that share a queue serialise (with the default, 4 chains are
+ * slower than 3), so the request is GRANTED only up to what the variable, as
+ * the library finds it at pt_create, leaves room for: 3 chains when it is unset
+ * or <= 7, GPU_MAX_HW_QUEUES - 4 beyond that.  The call still returns PT_OK;
+ * pt_frames_in_flight() returns the number in effect.  Memory: one more
+ * accumulation buffer per chain beyond the first.
  *
  * Large calls.  A pixel belongs to one lane per launch, so one long launch over
  * few pixels per lane (2.3 at 1280x720) ends with most lanes idle.  On frames
@@ -254,6 +259,7 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
  * the single launch's up to float summation order.  (Environment variable
  * PT_AMD_CHUNK=0, read at pt_create, keeps every call one launch.) */
 int pt_set_frames_in_flight(PtContext* ctx, uint32_t n);
+uint32_t pt_frames_in_flight(PtContext* ctx);
 int pt_flush(PtContext* ctx);
 /* Resolve the accumulation buffer into the context's display buffer
  * (convertToRGBAKernel / the CPU accumulate+gamma loop).  Asynchronous. */
@@ -297,15 +303,24 @@ int pt_reset_counters(PtContext* ctx);
 int pt_valu_peak(PtContext* ctx, uint32_t packed, uint32_t iters, double* out_tflops);
 
 /* -- reference call shape ---------------------------------------------------- */
-/* launchRenderKernel(float4* output, w, h, frame_count, grid, block)
+/* extern "C" void launchRenderKernel(float4* output, uint32_t width, uint32_t height,
+ *                                    uint32_t frame_count, dim3 grid, dim3 block)
  * (raytracer_kernel.cuh:51, raytracer_kernel.cu:325-327) on the context made
  * current by pt_make_current(): one more sample per pixel, running mean in
- * `output` (device, caller-owned); frame_count == 0 overwrites.  grid/block are
- * accepted as six integers and ignored (the launch shape is the library's). */
+ * `output` (device, caller-owned); frame_count == 0 overwrites.  grid and block
+ * are taken BY VALUE as the reference passes its dim3 (three uint32_t: PtDim3 has
+ * the layout and the x86-64 calling convention of CUDA's and HIP's dim3), and are
+ * ignored: the launch shape is the library's.  pt_host.hpp gives C++ hosts a
+ * `dim3` with the (x = 1, y = 1, z = 1) constructor, so the reference's call site
+ * (main.cu:208-212,287-288) compiles as it stands.
+ * The function returns void like the reference's; its error channel is
+ * pt_last_error(), which is empty after a launch that was enqueued (every entry
+ * point clears the thread's message on entry), so
+ * `if (*pt_last_error())` replaces CUDA_CHECK(cudaGetLastError()) (main.cu:289). */
+typedef struct PtDim3 { uint32_t x, y, z; } PtDim3;
 int pt_make_current(PtContext* ctx);
 void launchRenderKernel(void* output_float4, uint32_t width, uint32_t height, uint32_t frame_count,
-                        uint32_t grid_x, uint32_t grid_y, uint32_t grid_z,
-                        uint32_t block_x, uint32_t block_y, uint32_t block_z);
+                        PtDim3 grid, PtDim3 block);
 
 /* -- interactive camera (host only, no GPU needed) ---------------------------- */
 /* One iteration of the CPU app's input handling (cpu_pathtracer/src/main.cpp:157-195):

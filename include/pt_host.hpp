@@ -58,6 +58,8 @@ using Point3d = Vec3_t;
 inline Vec3_t operator+(const Vec3_t& a, const Vec3_t& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 inline Vec3_t operator-(const Vec3_t& a, const Vec3_t& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline Vec3_t operator*(const Vec3_t& a, double t) { return {a.x * t, a.y * t, a.z * t}; }
+inline Vec3_t& operator+=(Vec3_t& a, const Vec3_t& b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }  // Vec3.cuh:71-76 (main.cu:181)
+inline Vec3_t& operator-=(Vec3_t& a, const Vec3_t& b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
 inline double dot(const Vec3_t& a, const Vec3_t& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline Vec3_t cross(const Vec3_t& u, const Vec3_t& v) {
     return {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
@@ -70,6 +72,21 @@ struct Color_t {
     Color_t(double r_, double g_, double b_) : r(r_), g(g_), b(b_) {}
 };
 using ColorDBL = Color_t;
+
+// ---- launch-shape and pixel types of the reference's call sites ------------------------------
+// main.cu:55,208-212,287-288 declares `float4* d_output`, `dim3 block(16, 16)`, `dim3 grid(...)` and passes both
+// dim3 by value to launchRenderKernel.  A host built with hipcc has HIP's own types (same layout; the overload
+// below forwards them); a plain g++ host gets them here.
+#ifdef HIP_INCLUDE_HIP_HIP_RUNTIME_API_H
+inline void launchRenderKernel(void* output, uint32_t width, uint32_t height, uint32_t frame_count, const ::dim3& grid, const ::dim3& block) {
+    ::launchRenderKernel(output, width, height, frame_count, PtDim3{grid.x, grid.y, grid.z}, PtDim3{block.x, block.y, block.z});
+}
+#else
+struct dim3 : PtDim3 {
+    constexpr dim3(uint32_t x_ = 1, uint32_t y_ = 1, uint32_t z_ = 1) : PtDim3{x_, y_, z_} {}
+};
+struct float4 { float x, y, z, w; };
+#endif
 
 // ---- materials ---------------------------------------------------------------------------
 class Material_t {

@@ -66,6 +66,11 @@ class PtRenderParams(C.Structure):
     ]
 
 
+class PtDim3(C.Structure):
+    """dim3 of the reference's launchRenderKernel call (raytracer_kernel.cuh:51), passed by value."""
+    _fields_ = [("x", C.c_uint32), ("y", C.c_uint32), ("z", C.c_uint32)]
+
+
 class PtCounters(C.Structure):
     _fields_ = [
         ("samples", C.c_uint64), ("rays", C.c_uint64), ("hits", C.c_uint64),

@@ -19,7 +19,8 @@ SYMBOLS = [
     "pt_set_camera", "pt_resize", "pt_bind_accum", "pt_reset", "pt_render", "pt_resolve", "pt_readback",
     "pt_readback_accum", "pt_upload_accum", "pt_sync", "pt_accum_device_ptr", "pt_display_device_ptr",
     "pt_primary_ids", "pt_counters", "pt_reset_counters", "pt_valu_peak", "pt_make_current",
-    "launchRenderKernel", "pt_builtin_scene", "pt_set_frames_in_flight", "pt_flush", "pt_fly_camera_step", "pt_reduce",
+    "launchRenderKernel", "pt_builtin_scene", "pt_set_frames_in_flight", "pt_frames_in_flight", "pt_flush",
+    "pt_fly_camera_step", "pt_reduce",
 ]
 
 _lib = None
@@ -73,17 +74,15 @@ def lib() -> C.CDLL:
     L.pt_reset_counters.argtypes = [ctx]
     L.pt_valu_peak.argtypes = [ctx, u32, u32, C.POINTER(C.c_double)]
     L.pt_make_current.argtypes = [ctx]
-    L.launchRenderKernel.argtypes = [vp] + [u32] * 9
+    L.launchRenderKernel.argtypes = [vp, u32, u32, u32, abi.PtDim3, abi.PtDim3]  # grid, block by value, like dim3
     L.launchRenderKernel.restype = None
     L.pt_set_frames_in_flight.argtypes = [ctx, u32]
+    L.pt_frames_in_flight.argtypes = [ctx]
+    L.pt_frames_in_flight.restype = u32
     L.pt_flush.argtypes = [ctx]
     L.pt_reduce.argtypes = [ctx, vp, C.c_int]
     L.pt_fly_camera_step.argtypes = [C.POINTER(abi.PtCamera), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double, u32]
     L.pt_builtin_scene.argtypes = [C.c_char_p, u32, u32, C.POINTER(abi.PtSceneSoA), C.POINTER(abi.PtCamera)]
-    for name in SYMBOLS:
-        fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("pt_last_error",):
-            pass
     _lib = L
     return L
 

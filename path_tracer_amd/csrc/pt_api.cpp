@@ -8,6 +8,7 @@
 // launchRenderKernel (:325-327) and Window_t::updateScreen's device half (Window.cuh:147-165).
 #include "../../include/pt.h"
 #include "pt_device.h"
+#include "pt_error.h"
 
 #include <dlfcn.h>
 
@@ -30,15 +31,7 @@ namespace {
 thread_local std::string g_err;
 thread_local PtContext* g_current = nullptr;
 
-int fail(int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
-}
+#define fail pt_fail
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -47,6 +40,17 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 }  // namespace
+
+int pt_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+void pt_clear_error() { g_err.clear(); }
 
 struct PtContext {
     int device = 0;
@@ -84,7 +88,9 @@ struct PtContext {
     uint32_t burst = 0;                // launches since the chains were last joined
     bool burst_displayed = false;      // some launch of the burst made a display pass
     uint32_t compute_units = 256;
-    uint32_t burst_chains = 3;         // chains of a burst that pt_render opens by itself: GPU_MAX_HW_QUEUES - 4, 3..8
+    uint32_t burst_chains = 3;         // most chains worth running at once: 3 on HIP's default 4 hardware queues, else
+                                       // GPU_MAX_HW_QUEUES - 4 (up to 8); the cap of pt_set_frames_in_flight and the
+                                       // size of a burst that pt_render opens by itself
     uint64_t* trace = nullptr;         // PT_AMD_TRACE=<file>: per-wave timeline of the last launch (PT_TRACE kernel builds)
     size_t trace_waves = 0;
     uint32_t resident_blocks[8] = {};  // per kernel build (nee, count, few)
@@ -96,7 +102,10 @@ struct PtContext {
 
 namespace {
 
+// First statement of every entry point that takes a context: clears the thread's error message (so it is
+// empty after a call that succeeds) and makes the context's device current.
 int use(PtContext* ctx) {
+    pt_clear_error();
     if (!ctx) return fail(PT_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
     return PT_OK;
@@ -109,19 +118,28 @@ int alloc_frame(PtContext* ctx, uint32_t w, uint32_t h) {
     if (w == ctx->width && h == ctx->height && ctx->display) return PT_OK;
     if (int rc = join_chains(ctx)) return rc;
     const size_t npix = (size_t)w * h;
-    if (ctx->accum_own) { HIP_TRY(hipFree(ctx->accum_own)); ctx->accum_own = nullptr; }
-    if (ctx->display) { HIP_TRY(hipFree(ctx->display)); ctx->display = nullptr; }
-    if (ctx->ids) { HIP_TRY(hipFree(ctx->ids)); ctx->ids = nullptr; }
-    HIP_TRY(hipMalloc((void**)&ctx->accum_own, npix * sizeof(float4)));
-    HIP_TRY(hipMalloc(&ctx->display, npix * 16));
-    HIP_TRY(hipMemsetAsync(ctx->accum_own, 0, npix * sizeof(float4), ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->display, 0, npix * 16, ctx->stream));
+    // the new buffers first, the swap only when both exist: a failed allocation leaves the old frame intact
+    float4* accum_new = nullptr;
+    void* display_new = nullptr;
+    hipError_t e = hipMalloc((void**)&accum_new, npix * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&display_new, npix * 16);
+    if (e == hipSuccess) e = hipMemsetAsync(accum_new, 0, npix * sizeof(float4), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(display_new, 0, npix * 16, ctx->stream);
+    if (e != hipSuccess) {
+        if (accum_new) (void)hipFree(accum_new);
+        if (display_new) (void)hipFree(display_new);
+        return fail(PT_ERR_HIP, "allocating a %ux%u frame failed: %s", w, h, hipGetErrorString(e));
+    }
+    // hipFree synchronises the device, so nothing queued still uses the old buffers when they go
+    if (ctx->accum_own) (void)hipFree(ctx->accum_own);
+    if (ctx->display) (void)hipFree(ctx->display);
+    if (ctx->ids) { (void)hipFree(ctx->ids); ctx->ids = nullptr; }
+    ctx->accum_own = accum_new;
+    ctx->display = display_new;
     ctx->width = w;
     ctx->height = h;
     ctx->display_bytes = 0;
-    if (ctx->accum_bound) {  // a bound buffer was sized for the old frame
-        ctx->accum_bound = false;
-    }
+    ctx->accum_bound = false;  // a bound buffer was sized for the old frame
     ctx->accum = ctx->accum_own;
     return PT_OK;
 }
@@ -411,6 +429,7 @@ const char* pt_last_error(void) { return g_err.c_str(); }
 uint32_t pt_abi_version(void) { return 2u; }
 
 int pt_create(int device_id, PtContext** out) {
+    pt_clear_error();
     if (!out) return fail(PT_ERR_INVALID, "out_ctx is null");
     *out = nullptr;
     int n = 0;
@@ -448,6 +467,7 @@ int pt_create(int device_id, PtContext** out) {
 }
 
 int pt_destroy(PtContext* ctx) {
+    pt_clear_error();
     if (!ctx) return PT_OK;
     (void)hipSetDevice(ctx->device);
     for (uint32_t c = 0; c < PT_MAX_CHAINS; ++c) {
@@ -841,8 +861,16 @@ int pt_set_frames_in_flight(PtContext* ctx, uint32_t n) {
     if (int rc = use(ctx)) return rc;
     if (n < 1 || n > PT_MAX_CHAINS) return fail(PT_ERR_INVALID, "frames in flight must be 1..%u, got %u", PT_MAX_CHAINS, n);
     if (int rc = join_chains(ctx)) return rc;
-    ctx->flight = n;
+    // Chains that share a hardware queue serialise (4 chains on HIP's default 4 queues: 7.6 Gsamples/s where 3
+    // run at 10.3), so the request is granted up to what GPU_MAX_HW_QUEUES leaves room for: 3 with the default,
+    // queues - 4 beyond it.  pt_frames_in_flight() tells the caller what it got.
+    ctx->flight = n < ctx->burst_chains ? n : ctx->burst_chains;
     return PT_OK;
+}
+
+uint32_t pt_frames_in_flight(PtContext* ctx) {
+    pt_clear_error();
+    return ctx ? ctx->flight : 0u;
 }
 
 int pt_sync(PtContext* ctx) {
@@ -888,6 +916,8 @@ int pt_primary_ids(PtContext* ctx, uint32_t* host_obj, uint32_t* host_mat) {
     if (int rc = use(ctx)) return rc;
     if (!ctx->have_scene) return fail(PT_ERR_STATE, "no scene uploaded");
     if (!ctx->have_camera) return fail(PT_ERR_STATE, "no camera set");
+    if (ctx->cd.width != ctx->width || ctx->cd.height != ctx->height)  // the kernel iterates the camera's pixels
+        return fail(PT_ERR_STATE, "frame was resized to %ux%u after the camera was set for %ux%u", ctx->width, ctx->height, ctx->cd.width, ctx->cd.height);
     const size_t npix = (size_t)ctx->width * ctx->height;
     if (!ctx->ids) HIP_TRY(hipMalloc((void**)&ctx->ids, 2 * npix * sizeof(uint32_t)));
     HIP_TRY(pt_launch_primary_ids(ctx->sd, ctx->cd, ctx->ids, ctx->ids + npix, ctx->stream));
@@ -939,12 +969,13 @@ int pt_valu_peak(PtContext* ctx, uint32_t packed, uint32_t iters, double* out_tf
 }
 
 int pt_make_current(PtContext* ctx) {
+    pt_clear_error();
     g_current = ctx;
     return PT_OK;
 }
 
-void launchRenderKernel(void* output, uint32_t width, uint32_t height, uint32_t frame_count, uint32_t, uint32_t, uint32_t,
-                        uint32_t, uint32_t, uint32_t) {
+void launchRenderKernel(void* output, uint32_t width, uint32_t height, uint32_t frame_count, PtDim3 /*grid*/, PtDim3 /*block*/) {
+    pt_clear_error();
     PtContext* ctx = g_current;
     if (!ctx) { fail(PT_ERR_STATE, "launchRenderKernel: no current context (pt_make_current)"); return; }
     if (!output) { fail(PT_ERR_INVALID, "launchRenderKernel: output is null"); return; }
@@ -955,7 +986,7 @@ void launchRenderKernel(void* output, uint32_t width, uint32_t height, uint32_t 
     PtRenderParams p{};
     p.integrator = PT_INTEGRATOR_PATH; p.max_depth = 50; p.rr_depth = 3; p.seed = 0x5EED0001u;  // :294, :233
     p.acc_mode = PT_ACC_RUNNING_MEAN;
-    (void)pt_render(ctx, frame_count, 1, &p);
+    (void)pt_render(ctx, frame_count, 1, &p);  // a failure leaves its message in pt_last_error()
     ctx->accum = saved; ctx->accum_bound = saved_bound;
 }
 

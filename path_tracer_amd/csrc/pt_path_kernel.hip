@@ -267,15 +267,16 @@ __device__ __forceinline__ void closest_hit_few(const DevSceneF& sc, const FewLd
 }
 
 // Solid-angle pdf of picking one of nl sphere lights uniformly and sampling its cone from P.
-// Returns 0 when P is inside the light.  cosmax / wc / dc2 are by-products for the sampler.
-__device__ __forceinline__ float light_pdf(float4 lt, int nl, V3 P, float& cosmax, V3& wc, float& dc2) {
+// Returns 0 when P is inside the light.  omc (= 1 - cos of the cone's half angle) / wc / dc2 are by-products
+// for the sampler.
+__device__ __forceinline__ float light_pdf(float4 lt, int nl, V3 P, float& omc, V3& wc, float& dc2) {
     wc = v3(lt.x - P.x, lt.y - P.y, lt.z - P.z);
     dc2 = dot(wc, wc);
-    cosmax = 0.0f;
+    omc = 0.0f;
     if (!(dc2 > lt.w)) return 0.0f;
     const float s2 = lt.w * rcp(dc2);
-    cosmax = fsqrt(fmaxf(0.0f, 1.0f - s2));
-    const float omc = s2 * rcp(1.0f + cosmax);  // 1 - cosmax without cancellation
+    const float cosmax = fsqrt(fmaxf(0.0f, 1.0f - s2));
+    omc = s2 * rcp(1.0f + cosmax);  // 1 - cosmax without cancellation
     return rcp(6.283185307179586f * omc * (float)nl);
 }
 
@@ -482,11 +483,15 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
                                 if (COUNT) c_nee++;
                                 const uint32_t j = __umulhi(pt_draw(key, slot, 4), (uint32_t)sc.nl);
                                 const float v1 = uni(pt_draw(key, slot, 5)), v2 = uni(pt_draw(key, slot, 6));
-                                float cosmax, dc2; V3 wc;
-                                const float pl = light_pdf(sc.lights[3 * j], sc.nl, p, cosmax, wc, dc2);
+                                float omc, dc2; V3 wc;
+                                const float pl = light_pdf(sc.lights[3 * j], sc.nl, p, omc, wc, dc2);
                                 if (pl > 0.0f) {
-                                    const float cost = 1.0f - v1 * (1.0f - cosmax);
-                                    const float sint = fsqrt(fmaxf(0.0f, 1.0f - cost * cost));
+                                    // uniform in the cone, written in the small quantity 1 - cos(theta) itself: a light 50
+                                    // units away subtends 1 - cosmax ~ 3e-5, which `1 - cosmax` and `1 - cos^2` would keep
+                                    // to three digits
+                                    const float omct = v1 * omc;
+                                    const float cost = 1.0f - omct;
+                                    const float sint = fsqrt(omct * (2.0f - omct));
                                     const V3 w = wc * rsq(dc2);
                                     V3 uu, vv; onb(w, uu, vv);
                                     const V3 ldir = normalized(uu * (cos2pi(v2) * sint) + vv * (sin2pi(v2) * sint) + w * cost);
@@ -741,18 +746,24 @@ __global__ __launch_bounds__(256) void pt_resolve_kernel(const float4* __restric
         ((float4*)out)[p] = make_float4(r, g, b, 1.0f);
     } else if (mode == 0u) {  // PT_RESOLVE_RGBA8_CUDA
         ((uint32_t*)out)[p] = pack_rgba8_cuda(r, g, b);
-    } else if (mode == 1u) {  // PT_RESOLVE_RGBA8_CPU: clamp, pow(1/2.2), *255 truncated
-        const float gr = powf(fminf(fmaxf(r, 0.0f), 1.0f), 1.0f / 2.2f);
-        const float gg = powf(fminf(fmaxf(g, 0.0f), 1.0f), 1.0f / 2.2f);
-        const float gb = powf(fminf(fmaxf(b, 0.0f), 1.0f), 1.0f / 2.2f);
-        ((uint32_t*)out)[p] = pack_rgba8_cuda(gr, gg, gb);
-    } else {  // PT_RESOLVE_RGB8_PPM: gamma, clamp, +0.5 rounding
+    } else if (mode == 1u) {  // PT_RESOLVE_RGBA8_CPU (main.cpp:229-234 + WindowX11.h:130-139)
+        // std::pow(std::clamp(c, 0.0, 1.0), 1.0/2.2) in double as the reference evaluates it, then the window's
+        // truncating *255 pack.  The pass is HBM-bound: three double pows per pixel ride along.
+        uint32_t c8[3];
+        const float c[3] = {r, g, b};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double v = pow(fmin(fmax((double)c[k], 0.0), 1.0), 1.0 / 2.2);
+            c8[k] = (uint32_t)(uint8_t)(v * 255.0);
+        }
+        ((uint32_t*)out)[p] = (c8[0] << 16) | (c8[1] << 8) | c8[2];
+    } else {  // PT_RESOLVE_RGB8_PPM: ColorDBL::gamma(2.2), clamp, *255 + 0.5 truncated (Camera.h:172-176, Color.h:45-51,86-91)
         uint8_t* o = (uint8_t*)out + 3ull * p;
         const float c[3] = {r, g, b};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float gm = powf(fmaxf(c[k], 0.0f), 1.0f / 2.2f);
-            o[k] = (uint8_t)(fminf(fmaxf(gm, 0.0f), 1.0f) * 255.0f + 0.5f);
+            const double gm = pow((double)c[k], 1.0 / 2.2);  // a negative mean gives NaN, which the clamp sends to 0 like std::clamp's comparisons
+            o[k] = (uint8_t)(fmin(fmax(gm, 0.0), 1.0) * 255.0 + 0.5);
         }
     }
 }

@@ -6,6 +6,7 @@
 // path_tracer_amd/scenes.py restates the same literals independently; tests/test_scenes.py
 // requires the two to agree bit for bit.
 #include "../../include/pt_host.hpp"
+#include "../csrc/pt_error.h"
 
 #include <cstring>
 #include <map>
@@ -162,14 +163,15 @@ thread_local std::map<std::string, Built> g_built;
 }  // namespace
 
 extern "C" int pt_builtin_scene(const char* name, uint32_t width, uint32_t height, PtSceneSoA* scene, PtCamera* camera) {
-    if (!name || !scene || !camera || width == 0 || height == 0) return PT_ERR_INVALID;
+    pt_clear_error();
+    if (!name || !scene || !camera || width == 0 || height == 0) return pt_fail(PT_ERR_INVALID, "pt_builtin_scene: null argument or zero frame size");
     const std::string n(name);
     Built b;
     if (n == "cpu_default") b = build_cpu_default(width, height);
     else if (n == "cuda_default") b = build_cuda_default(width, height);
     else if (n == "glass_stress") b = build_glass_stress(width, height);
     else if (n == "random4096") b = build_random4096(width, height);
-    else return PT_ERR_INVALID;
+    else return pt_fail(PT_ERR_INVALID, "pt_builtin_scene: no scene named '%s' (cpu_default, cuda_default, glass_stress, random4096)", name);
     Built& slot = g_built[n];
     slot = std::move(b);
     *scene = slot.flat.view();

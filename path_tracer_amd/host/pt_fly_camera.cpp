@@ -2,6 +2,7 @@
 // as a pure host function of the C ABI.  Compiled with -ffp-contract=off: every operation is one
 // IEEE double operation in the order the reference writes them.
 #include "../../include/pt.h"
+#include "../csrc/pt_error.h"
 
 #include <algorithm>
 #include <cmath>
@@ -11,7 +12,8 @@
 #endif
 
 extern "C" int pt_fly_camera_step(PtCamera* cam, double* yaw, double* pitch, double mouse_dx, double mouse_dy, uint32_t keys) {
-    if (!cam || !yaw || !pitch) return PT_ERR_INVALID;
+    pt_clear_error();
+    if (!cam || !yaw || !pitch) return pt_fail(PT_ERR_INVALID, "pt_fly_camera_step: camera, yaw and pitch must not be null");
     const double mouse_sensitivity = 0.002, move_speed = 0.1;  // main.cpp:137-138
     *yaw += mouse_dx * mouse_sensitivity;                                                                    // :157
     *pitch = std::clamp(*pitch - mouse_dy * mouse_sensitivity, -M_PI / 2.0 + 0.1, M_PI / 2.0 - 0.1);        // :158-159

@@ -81,6 +81,10 @@ class Renderer:
         """1..8 consecutive sum-mode launches overlap on internal streams (include/pt.h)."""
         check(self._L.pt_set_frames_in_flight(self._ctx, n))
 
+    def frames_in_flight(self) -> int:
+        """The number of chains in effect (the request, capped by what GPU_MAX_HW_QUEUES leaves room for)."""
+        return int(self._L.pt_frames_in_flight(self._ctx))
+
     def reduce(self, nccl_comm, root: int = 0):
         """In-place RCCL sum of the accumulation buffer over the communicator's ranks (root < 0: all-reduce)."""
         check(self._L.pt_reduce(self._ctx, C.c_void_p(nccl_comm), int(root)))
@@ -160,7 +164,11 @@ class Renderer:
     def launch_render_kernel(self, dev_ptr: int, frame_count: int):
         """The reference's call shape: launchRenderKernel(output, w, h, frame_count, grid, block)."""
         check(self._L.pt_make_current(self._ctx))
-        self._L.launchRenderKernel(C.c_void_p(dev_ptr), self.width, self.height, frame_count, 0, 0, 0, 16, 16, 1)
+        grid = abi.PtDim3((self.width + 15) // 16, (self.height + 15) // 16, 1)  # main.cu:208-212
+        self._L.launchRenderKernel(C.c_void_p(dev_ptr), self.width, self.height, frame_count, grid, abi.PtDim3(16, 16, 1))
+        err = self._L.pt_last_error()  # the function returns void, like the reference's: this is its error channel
+        if err:
+            raise PtError(abi.PT_ERR_STATE, err.decode("utf-8", "replace"))
 
 
 # --- FLOP model of SURVEY.md §8(d) ------------------------------------------------------

@@ -33,14 +33,15 @@ def test_struct_sizes_match_the_header(tmp_path):
     src = tmp_path / "sizes.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "pt.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(PtSceneSoA), sizeof(PtCamera),'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(PtSceneSoA), sizeof(PtCamera),'
         ' sizeof(PtRenderParams), sizeof(PtCounters), offsetof(PtSceneSoA, mat_type), offsetof(PtCamera, width),'
-        ' offsetof(PtCounters, diffuse_updates)); return 0;}\n')
+        ' offsetof(PtCounters, diffuse_updates), sizeof(PtDim3), offsetof(PtDim3, z)); return 0;}\n')
     exe = tmp_path / "sizes"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     want = [C.sizeof(abi.PtSceneSoA), C.sizeof(abi.PtCamera), C.sizeof(abi.PtRenderParams), C.sizeof(abi.PtCounters),
-            abi.PtSceneSoA.mat_type.offset, abi.PtCamera.width.offset, abi.PtCounters.diffuse_updates.offset]
+            abi.PtSceneSoA.mat_type.offset, abi.PtCamera.width.offset, abi.PtCounters.diffuse_updates.offset,
+            C.sizeof(abi.PtDim3), abi.PtDim3.z.offset]
     assert got == want
 
 
@@ -52,6 +53,24 @@ def test_host_only_entry_points():
     assert L.pt_builtin_scene(b"cuda_default", 64, 36, C.byref(s), C.byref(c)) == 0
     assert s.num_spheres == 9 and c.width == 64
     assert L.pt_destroy(None) == 0  # destroying nothing is not an error
+
+
+def test_last_error_is_the_last_calls():
+    """pt_last_error() holds the message of the thread's last call: set by a failure, empty again after a call
+    that succeeds (launchRenderKernel returns void like the reference's, so this is its only error channel)."""
+    L = _lib.lib()
+    s, c = abi.PtSceneSoA(), abi.PtCamera()
+    assert L.pt_builtin_scene(b"no_such_scene", 64, 64, C.byref(s), C.byref(c)) == abi.PT_ERR_INVALID
+    assert b"no_such_scene" in L.pt_last_error()
+    assert L.pt_builtin_scene(b"cuda_default", 64, 36, C.byref(s), C.byref(c)) == 0
+    assert L.pt_last_error() == b""
+    # the reference's call shape, dim3 by value (raytracer_kernel.cuh:51): no context is current on this thread
+    assert L.pt_make_current(None) == 0
+    L.launchRenderKernel(C.c_void_p(16), 64, 36, 0, abi.PtDim3(4, 3, 1), abi.PtDim3(16, 16, 1))
+    assert b"no current context" in L.pt_last_error()
+    assert L.pt_frames_in_flight(None) == 0 and L.pt_last_error() == b""
+    assert L.pt_fly_camera_step(None, None, None, 0.0, 0.0, 0) == abi.PT_ERR_INVALID and L.pt_last_error()
+    assert L.pt_destroy(None) == 0 and L.pt_last_error() == b""
 
 
 def test_product_does_not_reference_the_oracle():

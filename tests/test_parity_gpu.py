@@ -21,12 +21,36 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# Every statistical bound below goes through _bound(): it asserts and records (measured, limit), and the module
+# writes the record to gpurun_out/parity_measured.json (copied to profiles/ per round).  Limits are set to at most
+# three times the value measured on the MI355X (recorded next to each), so a regression that triples the share of
+# paths that branch differently fails, instead of hiding under a generous constant.
+_MEASURED = {}
+
+
+def _bound(name, value, limit, at_least=False):
+    value, limit = float(value), float(limit)
+    _MEASURED[name] = {"measured": value, "limit": limit, "kind": "at_least" if at_least else "below"}
+    if at_least:
+        assert value >= limit, f"{name}: measured {value:.6g}, must be at least {limit:.6g}"
+    else:
+        assert value < limit, f"{name}: measured {value:.6g}, bound {limit:.6g}"
+
+
 @pytest.fixture(scope="module")
 def gpu():
     from path_tracer_amd.renderer import Renderer
     r = Renderer(0)
     yield r
     r.close()
+    try:
+        import json
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_measured.json"), "w") as f:
+            json.dump(_MEASURED, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
 
 
 def _setup(r, scene, cam):
@@ -60,7 +84,7 @@ def test_ids_cpu_default_full_size(gpu, oracle, running_app, hist):
     assert np.bincount(ids.ravel(), minlength=8).tolist() == hist   # the reference's own known answer
 
 
-@pytest.mark.parametrize("name,size", [("cuda_default", (1280, 720)), ("cuda_default", (1920, 1080)),
+@pytest.mark.parametrize("name,size", [("cuda_default", (1280, 720)), ("cuda_default", (1920, 1080)), ("cuda_default", (3840, 2160)),
                                         ("glass_stress", (1280, 720)), ("random4096", (480, 270)),
                                         ("cuda_default", (37, 21))])
 def test_ids_bit_exact(gpu, oracle, name, size):
@@ -109,9 +133,9 @@ def test_direct_matches_oracle(gpu, oracle):
     # differ in the last bit, which re-flips the rounding-governed self-shadow test of D6 for that
     # sample.  Pixels agree exactly where they do not, and in the mean everywhere.
     exact = np.isclose(gm, wm, rtol=1e-5, atol=1e-7).all(axis=2).mean()
-    assert exact > 0.80, exact
+    _bound("direct_320x180_8spp/pixels_exactly_equal", exact, 0.95, at_least=True)      # measured 0.9827
     # seed-to-seed standard deviation of this image mean is 3.2 % (heavy-tailed 50*cos/d^2 term)
-    assert abs(gm.mean() - wm.mean()) < 0.05 * wm.mean()
+    _bound("direct_320x180_8spp/rel_mean_diff", abs(gm.mean() - wm.mean()) / wm.mean(), 0.034)   # measured 0.0113
 
 
 def test_direct_config0_64spp_statistics(gpu, oracle):
@@ -126,8 +150,8 @@ def test_direct_config0_64spp_statistics(gpu, oracle):
     # two realisations of an estimator whose light term is decided by FP rounding:
     # about a fifth of the light samples flip between the two maths libraries
     rmse = float(np.sqrt(((np.clip(gm, 0, 1) - np.clip(wm, 0, 1)) ** 2).mean()))
-    assert rmse < 0.08, rmse
-    assert abs(np.clip(gm, 0, 1).mean() - np.clip(wm, 0, 1).mean()) < 0.01
+    _bound("direct_160x90_64spp/rmse_clamped", rmse, 0.08)                                      # measured 0.0487
+    _bound("direct_160x90_64spp/abs_mean_diff_clamped", abs(np.clip(gm, 0, 1).mean() - np.clip(wm, 0, 1).mean()), 0.001)   # measured 0.0002
     cpu8 = gpu.resolve_to_host(abi.RESOLVE_RGBA8_CPU)
     assert cpu8.shape == (90, 160) and cpu8.max() <= 0xFFFFFF
 
@@ -135,6 +159,32 @@ def test_direct_config0_64spp_statistics(gpu, oracle):
 # ----------------------------------------------------------------- T3: path integrator ---
 def _frac_differing(gm, wm, tol=1e-3):
     return float((np.abs(gm - wm).max(axis=2) > tol * (1.0 + np.abs(wm).max(axis=2))).mean())
+
+
+# share of pixels that hold a sample whose path branched differently under FP32 rounding (FMA contraction on the GPU,
+# none in the oracle) / relative difference of the image means: limits = 3 x the values measured on the MI355X in
+# round 2 (profiles/r2_parity_measured.json)
+_N, _M, _C = abi.FLAG_NEE_MIS, abi.FLAG_NEE_MIS | abi.FLAG_LIGHT_COLOUR, abi.FLAG_LIGHT_COLOUR
+#                                        measured -> limit                            measured -> limit
+PATH_FRAC_LIMIT = {("cuda_default", 0): 0.0034,   # 0.00111       (NEE: a light pick, a cone sample and a shadow test
+                   ("cuda_default", _N): 0.030,   # 0.01014        more per bounce that can branch)
+                   ("cuda_default", _C): 0.0034,  # 0.00111
+                   ("cuda_default", _M): 0.028,   # 0.00931
+                   ("glass_stress", 0): 0.0013,   # 0.00042
+                   ("cpu_default", 0): 0.0005}    # 0.00007 (one pixel of 14 400)
+PATH_MEAN_LIMIT = {("cuda_default", 0): 0.0016,   # 0.00051
+                   ("cuda_default", _N): 0.0007,  # 0.00022
+                   ("cuda_default", _C): 0.0020,  # 0.00065
+                   ("cuda_default", _M): 0.0008,  # 0.00025
+                   ("glass_stress", 0): 0.0002,   # 0.00004
+                   ("cpu_default", 0): 0.0007}    # 0.00023
+# random4096: coordinates reach 50 units, where one float ulp of |o - c|^2 (2.4e-4) is the size of the reference's ray
+# epsilon (1e-4, Ray.cuh:38) and of its origin offsets (1e-3; none for Glossy, Material.cuh:204).  Whether a scattered
+# ray re-hits the sphere it leaves is then decided by rounding, which FMA contraction (hipcc, as nvcc's default for the
+# reference) and the oracle's uncontracted arithmetic round differently: ~25x more paths branch than in the Cornell box.
+RANDOM4096_FRAC_LIMIT = {0: 0.030, _N: 0.15, _M: 0.15}        # measured 0.0106, 0.0635, 0.0635
+RANDOM4096_MEAN_LIMIT = {0: 0.011, _N: 0.02, _M: 0.02}         # measured 0.0036
+RANDOM4096_COUNTER_LIMIT = 0.05                                # measured <= 0.0186 (sphere_roots; glossy chains)
 
 
 @pytest.mark.parametrize("name,flags,depth", [
@@ -158,18 +208,40 @@ def test_path_matches_float_oracle(gpu, oracle, name, flags, depth):
     want = oracle.render_path(sc, cam, 0, 16, p, precision=32)
     assert np.all(got[..., 3] == 16) and np.isfinite(got).all()
     gm, wm = _mean(got), _mean(want)
-    assert _frac_differing(gm, wm) < 0.05
-    assert abs(gm.mean() - wm.mean()) < 0.02 * wm.mean() + 1e-4
+    tag = f"path_{name}_flags{flags}_160x90_16spp"
+    _bound(tag + "/frac_pixels_differing", _frac_differing(gm, wm), PATH_FRAC_LIMIT[(name, flags)])
+    _bound(tag + "/rel_mean_diff", abs(gm.mean() - wm.mean()) / wm.mean(), PATH_MEAN_LIMIT[(name, flags)])
 
 
-def test_path_random_spheres_matches_float_oracle(gpu, oracle):
+@pytest.mark.parametrize("flags", [0, abi.FLAG_NEE_MIS, abi.FLAG_NEE_MIS | abi.FLAG_LIGHT_COLOUR])
+def test_path_random_spheres_matches_float_oracle(gpu, oracle, flags):
+    """BASELINE config 5's scene (4096 spheres, 64 of them lights) at a size the oracle referees in seconds: primary
+    ids, the image, and the event counters; with PT_FLAG_NEE_MIS the light is picked among all 64."""
     sc, cam = scenes.random4096(96, 54)
-    p = abi.render_params(max_depth=16)
+    assert sc.num_spheres == 4096 and int((sc.arrays["mat_type"][sc.arrays["sph_mat"]] == abi.MAT_EMISSIVE).sum()) == 64
     _setup(gpu, sc, cam)
+    ids, mats = gpu.primary_ids()
+    oid, omat = oracle.primary_ids(sc, cam)
+    assert np.array_equal(ids, oid) and np.array_equal(mats, omat)
+    p = abi.render_params(max_depth=16, flags=flags | abi.FLAG_COUNTERS)
+    gpu.reset_counters()
     gpu.render(0, 4, p)
     got = gpu.accum()
-    want = oracle.render_path(sc, cam, 0, 4, p, precision=32)
-    assert _frac_differing(_mean(got), _mean(want)) < 0.05
+    want, oc = oracle.render_path(sc, cam, 0, 4, p, precision=32, counters=True)
+    assert np.all(got[..., 3] == 4) and np.isfinite(got).all()
+    tag = f"path_random4096_flags{flags}_96x54_4spp"
+    _bound(tag + "/frac_pixels_differing", _frac_differing(_mean(got), _mean(want)), RANDOM4096_FRAC_LIMIT[flags])
+    # ... most of which is numerical jitter, not a path that branched: a sphere of radius 0.3 seen from 50 units away
+    # has normals good to 1e-5 (p - c cancels six digits), so a grazing light sample's cosine differs by a fraction
+    # of a per cent between two correctly rounded evaluations.  At a 2 % tolerance only the branched paths remain.
+    _bound(tag + "/frac_pixels_differing_beyond_2pct", _frac_differing(_mean(got), _mean(want), tol=2e-2), 0.03)
+    _bound(tag + "/rel_mean_diff", abs(_mean(got).mean() - _mean(want).mean()) / _mean(want).mean(), RANDOM4096_MEAN_LIMIT[flags])
+    g, o = gpu.counters().as_dict(), oc.as_dict()
+    assert g["samples"] == o["samples"] == 96 * 54 * 4
+    for k in ("rays", "hits", "sphere_roots", "diffuse_updates", "nee_samples", "shadow_rays"):
+        _bound(f"{tag}/counter_{k}_rel_diff", abs(g[k] - o[k]) / max(o[k], 1), RANDOM4096_COUNTER_LIMIT)
+    if flags & abi.FLAG_NEE_MIS:
+        assert g["nee_samples"] > 0 and g["shadow_rays"] > 0
 
 
 def test_path_three_sigma_and_rmse(gpu, oracle):
@@ -187,9 +259,9 @@ def test_path_three_sigma_and_rmse(gpu, oracle):
     sigma = np.sqrt(var / N)
     # same sample set on both sides: the difference is far inside the estimator's own 3 sigma
     inside = np.abs(gm - mean) <= 3.0 * sigma + 1e-4
-    assert inside.mean() > 0.999, inside.mean()
+    _bound("three_sigma_64x36_4096spp/frac_inside", inside.mean(), 0.999, at_least=True)
     rmse = float(np.sqrt(((np.clip(gm, 0, 1) - np.clip(mean, 0, 1)) ** 2).mean()))
-    assert rmse < 1e-3 * np.sqrt(4096.0 / N), rmse
+    _bound("three_sigma_64x36_4096spp/rmse_clamped", rmse, 1e-3 * np.sqrt(4096.0 / N))   # north_star: RMSE < 1e-3 at 4096 spp
 
 
 def test_mis_on_equals_mis_off_in_expectation(gpu):
@@ -200,7 +272,7 @@ def test_mis_on_equals_mis_off_in_expectation(gpu):
         for s0 in range(0, 2048, 128):
             gpu.render(s0, 128, abi.render_params(flags=flags))
         means.append(_mean(gpu.accum()).mean(axis=(0, 1)))
-    np.testing.assert_allclose(means[0], means[1], rtol=0.02)
+    _bound("mis_on_vs_off_64x36_2048spp/max_rel_channel_mean_diff", np.abs(means[1] / means[0] - 1.0).max(), 0.001)   # measured 0.00033
 
 
 def test_counters_match_oracle(gpu, oracle):
@@ -277,7 +349,7 @@ def test_running_mean_mode_matches_oracle(gpu, oracle):
     got = gpu.accum()
     want = oracle.render_path(sc, cam, 0, 12, p, precision=32)
     assert np.all(got[..., 3] == 1.0)
-    assert _frac_differing(got[..., :3], want[..., :3]) < 0.05
+    _bound("running_mean_96x54_12frames/frac_pixels_differing", _frac_differing(got[..., :3], want[..., :3]), 0.0006)   # measured 0.00019
 
 
 def test_launch_render_kernel_shim(gpu):
@@ -307,17 +379,23 @@ def test_resolve_bit_exact_on_same_buffer(gpu, oracle):
         got = gpu.resolve_to_host(mode)
         want = oracle.resolve(acc, abi.ACC_SUM, mode).reshape(got.shape)
         assert np.array_equal(got, want), mode
-    # gamma modes go through powf on the device and pow on the host: at most one code value apart
-    for mode, shape in ((abi.RESOLVE_RGBA8_CPU, None), (abi.RESOLVE_RGB8_PPM, None)):
+    # the gamma modes evaluate std::pow in double in the reference's order (main.cpp:229-234; Color.h:45-51,86-91):
+    # byte work, bit-exact like the others
+    for mode in (abi.RESOLVE_RGBA8_CPU, abi.RESOLVE_RGB8_PPM):
         got = gpu.resolve_to_host(mode)
         want = oracle.resolve(acc, abi.ACC_SUM, mode).reshape(got.shape)
-        if mode == abi.RESOLVE_RGBA8_CPU:
-            for sh in (16, 8, 0):
-                d = np.abs(((got >> sh) & 255).astype(int) - ((want >> sh) & 255).astype(int))
-                assert d.max() <= 1 and (d > 0).mean() < 0.01
-        else:
-            d = np.abs(got.astype(int) - want.astype(int))
-            assert d.max() <= 1 and (d > 0).mean() < 0.01
+        assert np.array_equal(got, want), mode
+    # ... also on a buffer that exercises the clamps and the whole 8-bit range: a ramp of means from -0.1 to 1.2
+    ramp = np.zeros((90, 160, 4), np.float32)
+    ramp[..., 0] = np.linspace(-0.1, 1.2, 160 * 90, dtype=np.float32).reshape(90, 160) * 3.0
+    ramp[..., 1] = np.linspace(0.0, 1.0, 160 * 90, dtype=np.float32).reshape(90, 160)[::-1] * 3.0
+    ramp[..., 2] = (np.arange(160 * 90, dtype=np.float32).reshape(90, 160) % 256) / 255.0 * 3.0
+    ramp[..., 3] = 3.0
+    gpu.upload_accum(ramp)
+    for mode in (abi.RESOLVE_RGBA8_CUDA, abi.RESOLVE_RGBA8_CPU, abi.RESOLVE_FLOAT_MEAN, abi.RESOLVE_RGB8_PPM):
+        got = gpu.resolve_to_host(mode)
+        want = oracle.resolve(ramp, abi.ACC_SUM, mode).reshape(got.shape)
+        assert np.array_equal(got, want), mode
 
 
 def test_fused_rgba8_equals_resolve_pass(gpu):
@@ -526,10 +604,11 @@ def test_kernel_builds_with_and_without_lane_parallel_mode_agree(gpu, oracle, mo
                 r.close()
         monkeypatch.delenv("PT_AMD_FEW_MAX")
         assert np.array_equal(imgs[0][..., 3], imgs[1][..., 3])
-        assert _frac_differing(_mean(imgs[0]), _mean(imgs[1])) < 0.03
+        _bound(f"lane_parallel_{name}/frac_differing_between_builds", _frac_differing(_mean(imgs[0]), _mean(imgs[1])), 0.002)   # measured 0
         want = oracle.render_path(sc, cam, 0, 8, p, precision=32)
-        for img in imgs:
-            assert _frac_differing(_mean(img), _mean(want)) < 0.05
+        for few, img in zip(("off", "on"), imgs):
+            _bound(f"lane_parallel_{name}/frac_differing_vs_oracle_{few}", _frac_differing(_mean(img), _mean(want)),
+                   0.0017 if name == "cuda_default" else 0.06)   # measured 0.00056 / 0.0204
 
 
 def test_frames_in_flight_random_call_sequences(gpu):
@@ -674,8 +753,8 @@ def test_composite_objects_ids_and_path(gpu, oracle):
     got = gpu.accum()
     want = oracle.render_path(sc, cam, 0, 16, p, precision=32)
     assert np.all(got[..., 3] == 16) and np.isfinite(got).all()
-    assert _frac_differing(_mean(got), _mean(want)) < 0.05
-    assert abs(_mean(got).mean() - _mean(want).mean()) < 0.01 * _mean(want).mean()
+    _bound("composite_200x120_16spp/frac_pixels_differing", _frac_differing(_mean(got), _mean(want)), 0.002)   # measured 0
+    _bound("composite_200x120_16spp/rel_mean_diff", abs(_mean(got).mean() - _mean(want).mean()) / _mean(want).mean(), 0.0005)   # measured 0
 
 
 # ------------------------------------------------------- depth of field (§8f.4) ---
@@ -696,10 +775,10 @@ def test_depth_of_field_matches_oracle(gpu, oracle):
     got = gpu.accum()
     want = oracle.render_path(sc, cam, 0, 16, p, precision=32)
     assert np.all(got[..., 3] == 16) and np.isfinite(got).all()
-    assert _frac_differing(_mean(got), _mean(want)) < 0.05
+    _bound("depth_of_field_240x135_16spp/frac_pixels_differing", _frac_differing(_mean(got), _mean(want)), 0.002)   # measured 0
     # it is a different image from the pinhole one (edges blur) with the same overall brightness
     assert np.abs(_mean(got) - _mean(pinhole)).mean() > 0.01
-    assert abs(_mean(got).mean() - _mean(pinhole).mean()) < 0.05 * _mean(pinhole).mean()
+    _bound("depth_of_field_240x135_16spp/rel_brightness_vs_pinhole", abs(_mean(got).mean() - _mean(pinhole).mean()) / _mean(pinhole).mean(), 0.025)   # measured 0.0084
 
 
 # ------------------------------------------------ general planes, empty and degenerate scenes ---
@@ -736,8 +815,9 @@ def test_general_planes_ids_and_path(gpu, oracle, flags):
     got = gpu.accum()
     want = oracle.render_path(sc, cam, 0, 16, p, precision=32)
     assert np.all(got[..., 3] == 16) and np.isfinite(got).all()
-    assert _frac_differing(_mean(got), _mean(want)) < 0.05
-    assert abs(_mean(got).mean() - _mean(want).mean()) < 0.01 * _mean(want).mean()
+    _bound(f"general_planes_flags{flags}_192x108_16spp/frac_pixels_differing", _frac_differing(_mean(got), _mean(want)),
+           0.006 if flags else 0.002)   # measured 0.0019 / 0
+    _bound(f"general_planes_flags{flags}_192x108_16spp/rel_mean_diff", abs(_mean(got).mean() - _mean(want).mean()) / _mean(want).mean(), 0.0005)   # measured 1.5e-5 / 0
 
 
 def test_empty_and_lightless_scenes(gpu, oracle):
@@ -780,11 +860,13 @@ def test_path_against_the_references_own_render(gpu):
     """images/cuda.png of the reference (a screenshot of the CUDA app: default scene, 1920x1080 client area, unknown
     sample count, 8 bits, truncated) as the fixture tests/golden/reference_cuda_screenshot_480x270.npz.  Same
     scene, camera, resolution; 1024 samples; clamp as convertToRGBAKernel does; 4x4 box filter like the fixture.
-    Measured: MAE 0.011 (2.8 of 255 levels), channel means +0.5...+1.3 % (0.8 % of that is the screenshot's
-    truncation to 8 bits)."""
-    import os
+    Whole image, then object by object (tests/screenshot_regions.py: every wall, sphere, light and the tetrahedron,
+    delimited by the bit-exact primary ids), so that one wrong BSDF cannot hide in the average."""
+    from tests.screenshot_regions import pure_cells, region_stats
     ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_cuda_screenshot_480x270.npz"))["rgb"].astype(np.float64) / 255.0
     sc, cam = scenes.cuda_default(1920, 1080)
+    _setup(gpu, sc, cam)
+    cells = pure_cells(gpu.primary_ids()[0], 4)
     for flags in (0, abi.FLAG_NEE_MIS):             # the MIS estimator has the same expectation
         _setup(gpu, sc, cam)
         for s0 in range(0, 1024, 64):
@@ -793,10 +875,29 @@ def test_path_against_the_references_own_render(gpu):
         disp = np.clip(acc[..., :3] / acc[..., 3:4], 0.0, 1.0).astype(np.float64)
         small = disp.reshape(270, 4, 480, 4, 3).mean(axis=(1, 3))
         d = np.abs(small - ref)
-        assert d.mean() < 0.02, d.mean()
-        assert np.sqrt((d ** 2).mean()) < 0.05
-        assert np.all(np.abs(small.mean(axis=(0, 1)) / ref.mean(axis=(0, 1)) - 1.0) < 0.025)
-        assert np.abs(small[:, ::-1] - ref).mean() > 0.1   # the mirrored image does not match
+        tag = f"screenshot_flags{flags}"
+        _bound(tag + "/mae", d.mean(), SCREENSHOT_LIMITS["mae"])
+        _bound(tag + "/rmse", np.sqrt((d ** 2).mean()), SCREENSHOT_LIMITS["rmse"])
+        _bound(tag + "/max_rel_channel_mean_diff", np.abs(small.mean(axis=(0, 1)) / ref.mean(axis=(0, 1)) - 1.0).max(), SCREENSHOT_LIMITS["channel_mean"])
+        _bound(tag + "/mirrored_image_mae", np.abs(small[:, ::-1] - ref).mean(), 0.1, at_least=True)   # negative control
+        regions = region_stats(small, ref, cells)
+        assert set(SCREENSHOT_REGION_LIMITS) <= set(regions), sorted(regions)
+        for name, st in regions.items():
+            _bound(f"{tag}/region/{name}/mean_colour_diff", st["mean_diff"], SCREENSHOT_REGION_LIMITS.get(name, 0.05))
+        # the lights are white in the reference's render (its kernel ignores makeEmissive's colour)
+        for name in ("main light", "blue light", "orange light"):
+            assert min(regions[name]["ref_mean"]) > 0.99
+
+
+# measured on the MI355X in round 2 (profiles/r2_parity_measured.json); limits <= 3 x measured, floor 0.01 for the
+# regions (the screenshot itself is a noisy frame of unknown sample count, truncated to 8 bits)
+SCREENSHOT_LIMITS = {"mae": 0.02, "rmse": 0.05, "channel_mean": 0.025}     # measured 0.0124, 0.0319, 0.0125
+SCREENSHOT_REGION_LIMITS = {                                               # measured (1024 samples, both estimators)
+    "floor": 0.01, "left wall (red)": 0.01, "right wall (green)": 0.01,    # 0.0027, 0.0015, 0.0012
+    "ceiling": 0.02, "back wall (mirror)": 0.011,                          # 0.0067, 0.0036
+    "glass sphere": 0.01, "glossy sphere": 0.01, "metal sphere": 0.0174,   # 0.0025, 0.0025, 0.0058
+    "main light": 0.01, "blue light": 0.01, "orange light": 0.01,          # 0.0001, 0, 0.0010
+    "tetrahedron": 0.0195}                                                 # 0.0065
 
 
 # ----------------------------------------------------- committed golden fixtures ---
@@ -815,19 +916,19 @@ def test_gpu_against_committed_golden_frames(gpu):
         got, want = gpu.accum(), g[key]
         assert np.array_equal(got[..., 3], want[..., 3])
         # FP32 with and without FMA contraction: a few per cent of the pixels hold a sample whose path branched differently
-        assert _frac_differing(_mean(got), _mean(want)) < 0.05
-        assert abs(_mean(got).mean() - _mean(want).mean()) < 0.02 * _mean(want).mean()
+        _bound(f"golden_{key}/frac_pixels_differing", _frac_differing(_mean(got), _mean(want)), 0.021 if flags else 0.0025)   # measured 0.0069 / 0.00077 (one pixel)
+        _bound(f"golden_{key}/rel_mean_diff", abs(_mean(got).mean() - _mean(want).mean()) / _mean(want).mean(), 0.0043 if flags else 0.0104)   # measured 0.0014 / 0.0035
     sc, cam = scenes.cpu_default(64, 36)
     _setup(gpu, sc, cam)
     gpu.render(0, 4, abi.render_params(integrator=abi.INTEGRATOR_DIRECT))
     got, want = gpu.accum(), g["cpu_default_direct_4spp"]
     assert np.array_equal(got[..., 3], want[..., 3])
     # deterministic terms exact; the light term flips on FP rounding, so compare the frame mean
-    assert abs(got[..., :3].mean() - want[..., :3].mean()) < 0.05 * want[..., :3].mean()
+    _bound("golden_cpu_default_direct_4spp/rel_mean_diff", abs(got[..., :3].mean() - want[..., :3].mean()) / want[..., :3].mean(), 0.0212)   # measured 0.0071
 
 
 # --------------------------------------------- headless driver and file formats (§8f.3) ---
-def test_headless_driver_ppm_checkpoint_resume_and_script(tmp_path):
+def test_headless_driver_ppm_checkpoint_resume_and_script(tmp_path, oracle):
     """tools/pt_headless (C++ host over the C ABI): P6 output, raw (sum, count) checkpoint, resume, scripted camera."""
     import json
     import os
@@ -851,9 +952,8 @@ def test_headless_driver_ppm_checkpoint_resume_and_script(tmp_path):
     a = np.fromfile(full, np.float32).reshape(H, W, 4)
     assert np.all(a[..., 3] == 8)
     # the PPM is the gamma-2.2, +0.5-rounded mean of the same buffer (Color.h:86-91)
-    img = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3).astype(int)
-    want = (np.clip(np.maximum(a[..., :3] / 8.0, 0.0) ** (1.0 / 2.2), 0.0, 1.0) * 255.0 + 0.5).astype(int)
-    assert np.abs(img - want).max() <= 1
+    img = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3)
+    assert np.array_equal(img, oracle.resolve(a, abi.ACC_SUM, abi.RESOLVE_RGB8_PPM).reshape(H, W, 3))   # bit-exact bytes
     # 4 spp, checkpoint, resume for 4 more == 8 spp in one go, bit for bit
     run("--spp", "4", "--spp-per-launch", "4", "--raw", str(half))
     run("--spp", "4", "--spp-per-launch", "4", "--resume", str(half), "--raw", str(rest))
@@ -962,8 +1062,8 @@ def test_crowded_scene_ids_and_path(gpu, oracle, flags):
     # sampling) of these pixels, and the GPU's FMA-contracted float arithmetic may not do much worse
     w64 = oracle.render_path(sc, cam, 0, 8, p, precision=64)
     rounding = _frac_differing(_mean(want), _mean(w64))
-    assert _frac_differing(_mean(got), _mean(want)) < 1.5 * rounding + 0.01
-    assert abs(_mean(got).mean() - _mean(want).mean()) < 0.005 * _mean(want).mean()
+    _bound(f"crowded_flags{flags}/frac_pixels_differing", _frac_differing(_mean(got), _mean(want)), 1.5 * rounding + 0.01)
+    _bound(f"crowded_flags{flags}/rel_mean_diff", abs(_mean(got).mean() - _mean(want).mean()) / _mean(want).mean(), 0.0037)   # measured 0.0012 / 0.0008
     g, o = gpu.counters().as_dict(), oc.as_dict()
     for k in ("rays", "hits", "sphere_roots"):
         assert abs(g[k] - o[k]) <= 0.01 * max(o[k], 1), (k, g[k], o[k])
@@ -971,8 +1071,9 @@ def test_crowded_scene_ids_and_path(gpu, oracle, flags):
 
 # -------------------------------------------------------------------------- error paths ---
 def test_error_behaviour():
-    from path_tracer_amd._lib import PtError
+    from path_tracer_amd._lib import PtError, check, lib
     from path_tracer_amd.renderer import Renderer
+    L = lib()
     r = Renderer(0)
     sc, cam = scenes.cuda_default(32, 18)
     with pytest.raises(PtError) as e:
@@ -1005,7 +1106,64 @@ def test_error_behaviour():
         r.render(0, 1, abi.render_params())  # the path integrator needs the CUDA camera model
     with pytest.raises(PtError):
         Renderer(99)
+    # pt_resize without a new camera: the id pass and the render refuse (the kernels iterate the camera's pixels)
+    r.set_camera(cam)
+    check(L.pt_resize(r._ctx, 64, 64))
+    r.width, r.height = 64, 64
+    for call in (lambda: r.primary_ids(), lambda: r.render(0, 1, abi.render_params())):
+        with pytest.raises(PtError) as e:
+            call()
+        assert e.value.code == abi.PT_ERR_STATE and "resized" in str(e.value)
+    r.set_camera(scenes.cuda_default(64, 64)[1])
+    assert r.primary_ids()[0].shape == (64, 64)
+    # the error message is the thread's LAST call's: a failure, then a good launchRenderKernel (which returns void,
+    # like the reference's; INTEGRATION.md tests pt_last_error() after it) leaves it empty
+    import torch
+    out = torch.zeros((64, 64, 4), device="cuda", dtype=torch.float32)
+    assert L.pt_set_frames_in_flight(r._ctx, 99) == abi.PT_ERR_INVALID and L.pt_last_error()
+    r.launch_render_kernel(out.data_ptr(), 0)
+    assert L.pt_last_error() == b""
+    r.sync()
+    assert float(out[..., 3].min()) == 1.0
+    # ... and a launch that fails says so through the same channel
+    check(L.pt_make_current(r._ctx))
+    L.launchRenderKernel(C.c_void_p(out.data_ptr()), 32, 32, 0, abi.PtDim3(2, 2, 1), abi.PtDim3(16, 16, 1))
+    assert b"does not match" in L.pt_last_error()
     r.close()
+
+
+def test_frames_in_flight_are_capped_by_the_hardware_queues():
+    """Chains that share a hardware queue serialise, so pt_set_frames_in_flight grants at most what
+    GPU_MAX_HW_QUEUES leaves room for: this process runs with 16 (tests/conftest.py) and gets all 8; a process
+    that leaves the variable unset gets 3 of the 8 it asks for, and renders the same samples."""
+    import subprocess
+    import sys
+    from path_tracer_amd.renderer import Renderer
+    r = Renderer(0)
+    try:
+        r.set_frames_in_flight(8)
+        assert r.frames_in_flight() == 8
+        r.set_frames_in_flight(2)
+        assert r.frames_in_flight() == 2
+    finally:
+        r.close()
+    code = (
+        "import numpy as np\n"
+        "from path_tracer_amd import abi, scenes\n"
+        "from path_tracer_amd.renderer import Renderer\n"
+        "r = Renderer(0); sc, cam = scenes.cuda_default(160, 90); r.set_scene(sc); r.set_camera(cam)\n"
+        "for s in range(7): r.render(s, 1, abi.render_params())\n"
+        "serial = r.accum(); r.reset()\n"
+        "r.set_frames_in_flight(8); assert r.frames_in_flight() == 3, r.frames_in_flight()\n"
+        "r.set_frames_in_flight(2); assert r.frames_in_flight() == 2\n"
+        "r.set_frames_in_flight(8)\n"
+        "for s in range(7): r.render(s, 1, abi.render_params())\n"
+        "got = r.accum(); assert np.all(got[..., 3] == 7); np.testing.assert_allclose(got, serial, rtol=2e-6, atol=1e-6)\n"
+        "r.close(); print('capped at 3')\n")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0 and "capped at 3" in p.stdout, p.stdout + p.stderr[-1500:]
 
 
 # ------------------------------------------------------------- full-size property checks ---
@@ -1028,12 +1186,35 @@ def test_full_size_720p_properties(gpu):
     assert m.max() <= 15.0 * 1.0001      # nothing brighter than an emitter seen directly
 
 
-def test_full_size_4k_smoke(gpu):
+def test_full_size_4k_properties(gpu):
+    """BASELINE config 3's frame (3840x2160).  The oracle cannot referee 8.3 M pixels of paths in a test, so: the
+    primary ids are bit-exact at this size (test_ids_bit_exact), and here the size-independent properties hold —
+    every pixel counted once per sample, the image independent of how the samples are cut into launches, the
+    sample split across 'GPUs' additive, and the 4K image box-filtered 3x the same picture as the 720p one."""
     sc, cam = scenes.cuda_default(3840, 2160)
+    p = abi.render_params()
     _setup(gpu, sc, cam)
-    gpu.render(0, 2, abi.render_params())
+    gpu.render(0, 4, p)
     a = gpu.accum()
-    assert np.all(a[..., 3] == 2) and np.isfinite(a).all()
+    assert np.all(a[..., 3] == 4) and np.isfinite(a).all() and a.min() >= 0.0
+    assert a[..., :3].max() <= 4 * 15.0 * 1.0001            # nothing brighter than an emitter seen directly
+    _setup(gpu, sc, cam)
+    gpu.render(0, 2, abi.render_params(pixels_per_wave=256))   # "GPU 0" of a two-way split, another launch shape
+    half = gpu.accum()
+    _setup(gpu, sc, cam)
+    gpu.render(2, 1, p)
+    gpu.render(3, 1, p)                                        # "GPU 1", progressive
+    other = gpu.accum()
+    np.testing.assert_allclose(half + other, a, rtol=2e-5, atol=1e-5)
+    m4k = _mean(a).reshape(720, 3, 1280, 3, 3).mean(axis=(1, 3))
+    sc7, cam7 = scenes.cuda_default(1280, 720)
+    _setup(gpu, sc7, cam7)
+    gpu.render(0, 36, p)                                       # as many samples per 720p pixel as its 3x3 4K pixels hold
+    m720 = _mean(gpu.accum())
+    _bound("full_size_4k/rel_mean_vs_720p", abs(m4k.mean() - m720.mean()) / m720.mean(), 0.0042)   # measured 0.0014
+    # both are 36-sample estimates of (nearly) the same pixel footprint: the difference is Monte-Carlo noise
+    coarse = lambda m: np.clip(m, 0, 1).reshape(45, 16, 80, 16, 3).mean(axis=(1, 3))
+    _bound("full_size_4k/coarse_mae_vs_720p", np.abs(coarse(m4k) - coarse(m720)).mean(), 0.03)   # measured 0.0117
     small = scenes.cuda_default(64, 36)
     gpu.set_scene(small[0])
     gpu.set_camera(small[1])
