@@ -222,6 +222,24 @@ int pt_reset(PtContext* ctx);
  * Asynchronous on the context's stream. */
 int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
               const PtRenderParams* params);
+/* pt_render for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for hosts that must not
+ * call hipMalloc while they render — code under HIP graph capture, tight serving loops, harnesses that forbid it.
+ * Adds samples [sample_begin, sample_begin + sample_count) of the path integrator to `accum_float4`, a caller-owned
+ * device buffer of width*height float4 (in/out, 16-byte aligned; width x height must be the camera's), as ONE
+ * serial launch on the context's stream.  The call makes no hipMalloc / hipFree / stream / event and no occupancy
+ * query: the kernel's only memory beyond its inputs and outputs, its ticket counters, lives in a 4 KB
+ * file-scope __device__ array (one copy per GPU, held until the process ends) whose address pt_create resolved.
+ * Scene and camera are the context's (uploaded at set-up); with fused_rgba8 the display goes to the context's
+ * display buffer.  Same kernel and same launch shape as a pt_render call that is not cut into parts, so for such a
+ * call the buffer is bit-identical to pt_render's.
+ * Limits: at most PT_NOALLOC_MAX_PIXELS pixels and PT_NOALLOC_MAX_SAMPLES samples per call (PT_ERR_CAPACITY
+ * beyond); path integrator only; PT_ERR_STATE while frames are in flight (pt_flush first).
+ * Every call on a GPU — from any context — shares that GPU's array and clears the part it uses on its stream:
+ * calls that overlap in time on one GPU race for the counters (undefined image); serialise them on one stream. */
+#define PT_NOALLOC_MAX_PIXELS (1u << 26) /* 8192 x 8192 */
+#define PT_NOALLOC_MAX_SAMPLES 4096u
+int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32_t height,
+                      uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* params);
 /* Frames in flight (1..8, default 1).  With n > 1, consecutive PT_ACC_SUM path
  * launches go round-robin to n internal streams, each with an accumulator of
  * its own, so launch k+1 fills the compute units that launch k leaves idle

@@ -77,6 +77,7 @@ struct PtContext {
     float* sink = nullptr;
     uint32_t* work_counter = nullptr;  // ticket counters of the path kernel: 8 chains x 2 alternating sets x 8 shards x 128 B
     uint32_t work_parity[PT_MAX_CHAINS] = {};  // per chain: which of its two sets the next launch uses
+    uint32_t* scratch = nullptr;               // this GPU's copy of the static scratch array (pt_render_noalloc), PT_SCRATCH_BYTES
     // frames in flight (pt_set_frames_in_flight): launch k of a burst goes to chain k % flight, which
     // has its own stream and its own accumulator; chain 0's accumulator is the context's (or the bound one)
     uint32_t flight = 1;
@@ -265,7 +266,7 @@ bool wants_parts(const PtContext* ctx, uint32_t sample_count, const PtRenderPara
     return part > 0 && sample_count >= (pipelined ? part + part / 2u + 1u : 12u);
 }
 
-int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm);
+int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm, float4* into = nullptr);
 
 // With frames in flight the launches join the open burst; without, the call is a burst of its own on
 // `burst_chains` chains, folded before it returns, and a fused display is made from the folded sums.  The
@@ -299,11 +300,16 @@ int render_in_parts(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count
 }
 
 // One launch of the path kernel for samples [sample_begin, sample_begin + sample_count) (arguments validated by pt_render).
-int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm) {
-    const bool pipelined = ctx->flight > 1 && can_overlap(ctx, prm);
+// `into` != nullptr is pt_render_noalloc's launch: one serial launch into the caller's buffer with the ticket counters
+// in the device's static scratch array; nothing on that path allocates, queries or creates anything.
+int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm, float4* into) {
+    const bool noalloc = into != nullptr;
+    const bool pipelined = !noalloc && ctx->flight > 1 && can_overlap(ctx, prm);
     uint32_t chain = 0;
     hipStream_t stream = ctx->stream;
-    if (pipelined) {
+    if (noalloc) {
+        // (pt_render_noalloc has checked that no burst is open)
+    } else if (pipelined) {
         if (ctx->burst == 0) {
             if (int rc = prepare_chains(ctx)) return rc;
             HIP_TRY(hipEventRecord(ctx->fork_event, ctx->stream));
@@ -315,7 +321,7 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
         if (int rc = join_chains(ctx)) return rc;
     }
     PathArgs a{};
-    a.accum = chain == 0 ? ctx->accum : ctx->chain_acc[chain];
+    a.accum = noalloc ? into : (chain == 0 ? ctx->accum : ctx->chain_acc[chain]);
     // a launch that overlaps others displays in a pass of its own behind it (pt_display_kernel): the mean over all chains
     const bool display_pass = pipelined && prm->fused_rgba8;
     a.rgba = (prm->fused_rgba8 && !display_pass) ? (uint32_t*)ctx->display : nullptr;
@@ -344,7 +350,10 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
     }
     const bool few = a.few_max > 0u;
     uint32_t& resident = ctx->resident_blocks[(nee ? 4 : 0) + (cnt ? 2 : 0) + (few ? 1 : 0)];
-    if (resident == 0) HIP_TRY(pt_path_resident_blocks(nee, cnt, few, ctx->device, &resident));
+    if (resident == 0) {  // (pt_create fills the table; this is the fall-back if its query failed)
+        if (noalloc) return fail(PT_ERR_STATE, "the occupancy of this kernel build was not established at pt_create");
+        HIP_TRY(pt_path_resident_blocks(nee, cnt, few, ctx->device, &resident));
+    }
     a.inv_tiles_x = 1.0f / (float)a.tiles_x;
     a.total_w = (float)(sample_begin + sample_count); a.inv_total_w = 1.0f / a.total_w;
     // Grid: no more waves than are resident at once.  Overlapping launches fill the chip together, so each
@@ -390,7 +399,16 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
     // join_chains() orders after it): each zeroes the set its successor on the same chain will use
     a.work_counter = ctx->work_counter + WORK_SET_WORDS * (2u * chain + ctx->work_parity[chain]);
     a.next_counter = ctx->work_counter + WORK_SET_WORDS * (2u * chain + (ctx->work_parity[chain] ^ 1u));
-    const char* trace_file = ctx->knob_trace.empty() ? nullptr : ctx->knob_trace.c_str();  // kernel-timeline experiments (tools/gpu_trace.py)
+    if (noalloc) {
+        // The static array is shared by every context on this GPU and keeps the last call's contents: this call's
+        // counter set is cleared here, on the stream, and the "next" set the kernel zeroes is the array's second
+        // half, which nobody relies on.  (A memset of >= 256 B on the launch's own stream is seen as zero by the
+        // kernel's atomics: MI355X_MICROARCH.md, zeroing across a kernel boundary.)
+        a.work_counter = ctx->scratch;
+        a.next_counter = ctx->scratch + WORK_SET_WORDS;
+        HIP_TRY(hipMemsetAsync(a.work_counter, 0, WORK_SET_WORDS * sizeof(uint32_t), stream));
+    }
+    const char* trace_file = (ctx->knob_trace.empty() || noalloc) ? nullptr : ctx->knob_trace.c_str();  // kernel-timeline experiments (tools/gpu_trace.py)
     if (trace_file) {
         const size_t waves = (size_t)blocks * 4u;
         if (ctx->trace_waves < waves) {
@@ -415,7 +433,7 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
         HIP_TRY(hipMemcpy(host.data(), ctx->trace, host.size() * 8, hipMemcpyDeviceToHost));
         if (FILE* f = fopen(trace_file, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
     }
-    ctx->work_parity[chain] ^= 1u;
+    if (!noalloc) ctx->work_parity[chain] ^= 1u;
     ctx->last_acc_mode = prm->acc_mode;
     if (prm->fused_rgba8) ctx->display_bytes = (size_t)ctx->width * ctx->height * 4;
     return PT_OK;
@@ -462,6 +480,12 @@ int pt_create(int device_id, PtContext** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->work_counter, 2 * PT_MAX_CHAINS * WORK_SET_WORDS * 4);
     if (e == hipSuccess) e = hipMemset(ctx->work_counter, 0, 2 * PT_MAX_CHAINS * WORK_SET_WORDS * 4);
     if (e != hipSuccess) { pt_destroy(ctx); return fail(PT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e)); }
+    // set-up for pt_render_noalloc, which may not allocate or query: the address of this GPU's copy of the static
+    // scratch array (resolving it also loads the code object on the device) and the occupancy of every kernel build
+    e = pt_scratch_setup(device_id, &ctx->scratch);
+    if (e != hipSuccess) { pt_destroy(ctx); return fail(PT_ERR_HIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", device_id, hipGetErrorString(e)); }
+    for (int v = 0; v < 8; ++v)
+        if (pt_path_resident_blocks((v & 4) != 0, (v & 2) != 0, (v & 1) != 0, device_id, &ctx->resident_blocks[v]) != hipSuccess) ctx->resident_blocks[v] = 0;
     *out = ctx;
     return PT_OK;
 }
@@ -804,6 +828,34 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
         return fail(PT_ERR_INVALID, "the running-mean mode adds one sample per launch, like renderKernel");
     if (wants_parts(ctx, sample_count, prm)) return render_in_parts(ctx, sample_begin, sample_count, prm);
     return launch_path(ctx, sample_begin, sample_count, prm);
+}
+
+int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32_t height, uint32_t sample_begin,
+                      uint32_t sample_count, const PtRenderParams* prm) {
+    if (int rc = use(ctx)) return rc;
+    if (!prm) return fail(PT_ERR_INVALID, "params is null");
+    if (!accum_float4 || ((uintptr_t)accum_float4 & 15u) != 0) return fail(PT_ERR_INVALID, "the accumulation buffer must be a 16-byte aligned device pointer");
+    if (!ctx->have_scene) return fail(PT_ERR_STATE, "no scene uploaded");
+    if (!ctx->have_camera) return fail(PT_ERR_STATE, "no camera set");
+    if ((uint64_t)width * height > PT_NOALLOC_MAX_PIXELS)
+        return fail(PT_ERR_CAPACITY, "pt_render_noalloc: %ux%u exceeds the maximum of %u pixels per call", width, height, PT_NOALLOC_MAX_PIXELS);
+    if (sample_count > PT_NOALLOC_MAX_SAMPLES)
+        return fail(PT_ERR_CAPACITY, "pt_render_noalloc: %u samples exceed the maximum of %u per call", sample_count, PT_NOALLOC_MAX_SAMPLES);
+    if (width != ctx->cf.width || height != ctx->cf.height)
+        return fail(PT_ERR_INVALID, "pt_render_noalloc: %ux%u does not match the camera's %ux%u", width, height, ctx->cf.width, ctx->cf.height);
+    if (ctx->cf.width != ctx->width || ctx->cf.height != ctx->height)
+        return fail(PT_ERR_STATE, "frame was resized to %ux%u after the camera was set for %ux%u", ctx->width, ctx->height, ctx->cf.width, ctx->cf.height);
+    if (sample_count == 0) return PT_OK;
+    if ((uint64_t)sample_begin + sample_count > 0xFFFFFFFFull) return fail(PT_ERR_INVALID, "sample range overflows 32 bits");
+    if (prm->integrator != PT_INTEGRATOR_PATH) return fail(PT_ERR_INVALID, "pt_render_noalloc runs the path integrator");
+    if (ctx->cd.model != PT_CAMERA_CUDA) return fail(PT_ERR_INVALID, "the path integrator uses the CUDA camera model");
+    if (prm->acc_mode > PT_ACC_RUNNING_MEAN) return fail(PT_ERR_INVALID, "unknown acc_mode %u", prm->acc_mode);
+    if (prm->max_depth == 0) return fail(PT_ERR_INVALID, "max_depth must be at least 1");
+    if (prm->acc_mode == PT_ACC_RUNNING_MEAN && sample_count != 1)
+        return fail(PT_ERR_INVALID, "the running-mean mode adds one sample per launch, like renderKernel");
+    if (ctx->burst != 0) return fail(PT_ERR_STATE, "frames are in flight: call pt_flush first (folding them launches on other streams)");
+    if (!ctx->scratch) return fail(PT_ERR_STATE, "the scratch array was not resolved at pt_create");
+    return launch_path(ctx, sample_begin, sample_count, prm, (float4*)accum_float4);
 }
 
 int pt_resolve(PtContext* ctx, uint32_t mode) {

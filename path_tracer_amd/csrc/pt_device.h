@@ -89,6 +89,13 @@ struct DevCamD {
     double half_w, half_h;
 };
 
+// ---- static scratch of pt_render_noalloc (pt_path_kernel.hip) ---------------------------
+// One array per GPU, 4 KB: two ticket-counter sets of the path kernel (8 shards x 128 B each).  The two limits are
+// the entry point's stated maxima (include/pt.h); the counters themselves do not grow with the frame.
+constexpr uint32_t PT_SCRATCH_BYTES = 4096;
+// Resolves (once per device, with that device current) and returns the device address of this GPU's copy.
+hipError_t pt_scratch_setup(int device, uint32_t** out);
+
 // ---- launchers implemented in the .hip translation units ------------------------------
 hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArgs& a, bool nee, bool count, bool few,
                           uint32_t blocks, hipStream_t stream);

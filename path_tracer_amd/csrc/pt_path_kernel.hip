@@ -25,6 +25,37 @@
 
 #include <float.h>
 
+#include <mutex>
+
+// ---- scratch of the entry point that allocates nothing (pt_render_noalloc, include/pt.h) ------------------
+// The path kernel's only memory beyond its inputs and outputs is its ticket counters.  pt_render takes them from a
+// hipMalloc made at pt_create; callers that cannot allocate (HIP graph capture, serving loops) get them from this
+// file-scope array instead: 4 KB, one copy per GPU the library runs on, held until the process ends.  In HOST code
+// the name `scratch` is only a handle for HIP_SYMBOL: its device address is resolved below, once per device, and
+// that pointer — never the name — is what kernels, memsets and copies are given.
+static __device__ __align__(256) uint32_t scratch[PT_SCRATCH_BYTES / sizeof(uint32_t)];
+
+namespace {
+constexpr int PT_MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+uint32_t* g_scratch_ptr[PT_MAX_DEVICES] = {};  // per device: each GPU holds its own copy at its own address
+}  // namespace
+
+// Called by pt_create with `device` current.
+hipError_t pt_scratch_setup(int device, uint32_t** out) {
+    if (device < 0 || device >= PT_MAX_DEVICES || !out) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = static_cast<uint32_t*>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 // (The number of lanes that must have ended their path before the regeneration steps are entered is a
 // launch argument, PathArgs::regen_min: 12 for one-sample launches, where every path end costs a flush, a
 // pull and a camera ray, +2 %; 1 otherwise, where larger values lose 1-3 %.)

@@ -110,6 +110,10 @@ class Renderer:
     def render(self, sample_begin: int, sample_count: int, params: abi.PtRenderParams):
         check(self._L.pt_render(self._ctx, sample_begin, sample_count, C.byref(params)))
 
+    def render_noalloc(self, dev_ptr: int, sample_begin: int, sample_count: int, params: abi.PtRenderParams):
+        """pt_render_noalloc: one serial launch into a caller-owned device buffer; allocates nothing (include/pt.h)."""
+        check(self._L.pt_render_noalloc(self._ctx, C.c_void_p(dev_ptr), self.width, self.height, sample_begin, sample_count, C.byref(params)))
+
     def resolve(self, mode: int):
         check(self._L.pt_resolve(self._ctx, mode))
 
