@@ -96,8 +96,8 @@ struct PtContext {
     size_t trace_waves = 0;
     uint32_t resident_blocks[8] = {};  // per kernel build (nee, count, few)
     // tuning / tracing knobs for tools/gpu_ab.py and tools/gpu_trace.py, read once at pt_create
-    // (PT_AMD_FEW_MAX, PT_AMD_MAX_BLOCKS, PT_AMD_CHUNK, PT_AMD_REGEN_MIN, PT_AMD_TRACE); -1 / empty = not set
-    int knob_few_max = -1, knob_max_blocks = -1, knob_chunk = -1, knob_regen_min = -1;
+    // (PT_AMD_FEW_MAX, PT_AMD_MAX_BLOCKS, PT_AMD_CHUNK, PT_AMD_REGEN_MIN, PT_AMD_IDLE_MIN, PT_AMD_PREFETCH, PT_AMD_TRACE); -1 / empty = not set
+    int knob_few_max = -1, knob_max_blocks = -1, knob_chunk = -1, knob_regen_min = -1, knob_idle_min = -1, knob_prefetch = -1;
     std::string knob_trace;
 };
 
@@ -386,13 +386,25 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
     a.units_per_grab = upg < 1u ? 1u : (upg > 65536u ? 65536u : upg);
     uint32_t blocks = (units / a.units_per_grab + 3u) / 4u;  // no more waves than tickets ...
     if (blocks > cap) blocks = cap;                          // ... and no more than the cap
-    // One-sample launches: every path end costs a flush, a pull and a camera ray (~150 instructions at a few
-    // lanes), so those steps wait for 12 lanes (+2 %, serial +5 %) -- unless a trip of waiting costs more than
-    // that (large scenes: 12 lanes idle through a 4096-sphere loop lose 6 %).
-    a.regen_min = 1u;
-    if (sample_count == 1u) { const uint32_t r = 4800u / (serial_cost ? serial_cost : 1u); a.regen_min = r > 12u ? 12u : r; }
+    // Regeneration (pt_path_kernel.hip, end of the loop body).  Camera rays are prepared one ahead, in batches: the
+    // batch runs once 32 lanes of a wave lack a prepared ray (4K, 16 spp: 24-48 all within 1 %, 8 loses 5 %).  Taking the
+    // next PIXEL ahead of time is right only when a lane has many pixels to go through: at 720p a resident lane gets 2.3
+    // pixels per launch, and a pixel held in reserve by a lane that is busy with a long path is a pixel an idle lane
+    // cannot take (-13 % on serial 720p / 1 spp launches, -19 % on `random4096`).  Without it a lane that ends a
+    // pixel waits for its next one; in one-sample launches of small scenes every path end is such a wait, and the
+    // pull + camera ray (~150 instructions) then waits for 12 idle lanes (+2 %, serial +5 %) -- unless a trip of
+    // waiting costs more than that (large scenes: 12 lanes idle through a 4096-sphere loop lose 6 %).
+    a.regen_min = 32u;
+    a.idle_min = 1u;
+    if (sample_count == 1u) { const uint32_t r = 4800u / (serial_cost ? serial_cost : 1u); a.idle_min = r > 12u ? 12u : r; }
+    // (launches that overlap others lose less to a withheld pixel -- another launch's lanes fill in: 720p, 16 spp, 8 in
+    //  flight +3 % with it, `random4096` -7 %)
+    a.prefetch_pixels = ((uint64_t)ctx->width * ctx->height >= (uint64_t)cap * 256u * 8u || (pipelined && sample_count > 1u && serial_cost <= 800u)) ? 1u : 0u;
     if (ctx->knob_regen_min >= 0) a.regen_min = (uint32_t)ctx->knob_regen_min;
+    if (ctx->knob_idle_min >= 0) a.idle_min = (uint32_t)ctx->knob_idle_min;
+    if (ctx->knob_prefetch >= 0) a.prefetch_pixels = (uint32_t)ctx->knob_prefetch;
     if (a.regen_min < 1u) a.regen_min = 1u;
+    if (a.idle_min < 1u) a.idle_min = 1u;
     if (ctx->knob_max_blocks > 0 && blocks > (uint32_t)ctx->knob_max_blocks) blocks = (uint32_t)ctx->knob_max_blocks;
     if (blocks < 8u) blocks = 8u;                            // every shard needs a block to serve its tiles
     // launches of one chain are ordered on its stream (chain 0 also serves unpipelined launches, which
@@ -467,6 +479,8 @@ int pt_create(int device_id, PtContext** out) {
     if (const char* e = getenv("PT_AMD_TRACE")) ctx->knob_trace = e;
     if (const char* e = getenv("PT_AMD_CHUNK")) ctx->knob_chunk = atoi(e);
     if (const char* e = getenv("PT_AMD_REGEN_MIN")) ctx->knob_regen_min = atoi(e);
+    if (const char* e = getenv("PT_AMD_IDLE_MIN")) ctx->knob_idle_min = atoi(e);
+    if (const char* e = getenv("PT_AMD_PREFETCH")) ctx->knob_prefetch = atoi(e);
     if (const char* e = getenv("GPU_MAX_HW_QUEUES")) {  // HIP reads the same variable when it initialises
         const int q = atoi(e) - 4;
         ctx->burst_chains = q < 3 ? 3u : (q > (int)PT_MAX_CHAINS ? PT_MAX_CHAINS : (uint32_t)q);

@@ -62,7 +62,9 @@ struct PathArgs {
     uint32_t num_tiles;
     uint32_t width, height;     // frame size (filled by pt_launch_path from the camera)
     uint32_t few_max;           // lane-parallel intersection when at most this many lanes of a wave trace
-    uint32_t regen_min;         // the regeneration steps wait until this many lanes want them (or none traces)
+    uint32_t regen_min;         // camera rays are prepared ahead in a batch once this many lanes lack one ...
+    uint32_t idle_min;          // ... or once this many lanes sit idle for lack of one (or no lane traces)
+    uint32_t prefetch_pixels;   // != 0: lanes take their next pixel while they still trace (launches with many pixels per lane)
     uint64_t* trace;            // per-wave timeline, 16 x u64 per wave (PT_TRACE kernel builds only; else nullptr)
 };
 

@@ -127,9 +127,33 @@ __device__ __forceinline__ cf4 as_const(const float4* p) {
 #pragma clang diagnostic pop
 }
 
-// t <= RAY_MAX_T is folded into the running minimum: it starts at the next float above 1e4, so
-// `t < tbest` implies `t <= 1e4` and one compare per primitive disappears.
+// The running closest hit.  The reference accepts a candidate when `t >= 1e-4 && t < tbest` (and t <= 1e4, which is
+// folded into the initial tbest: the next float above 1e4, so `t < tbest` implies `t <= 1e4`).  Non-negative floats
+// order like their bit patterns, so with k = bits(t) - bits(1e-4) in unsigned arithmetic that condition is exactly
+// `k < bits(tbest) - bits(1e-4)`: a t below 1e-4 wraps to a huge k, a negative t, an infinity or a NaN has bits above
+// every valid tbest.  The minimum is therefore carried biased (`tb`), one unsigned compare per candidate, and
+// unbiased once after the loops.  The update is a real branch over two moves (an exec-masked region), not two
+// selects: on gfx950 a v_cmp + s_and + 2 v_cndmask update costs 5.7 FMA issue slots, v_cmp + 2 v_mov under exec 4.2
+// (tools/ubench/valu_rates.hip, profiles/r2_valu_rates.json); the empty asm keeps hipcc from if-converting it back.
 constexpr float T_BEST_INIT = 10000.0009765625f;
+constexpr uint32_t EPS_BITS = 0x38D1B717u;                 // bits of 1e-4f (RAY_MIN_T)
+constexpr uint32_t TB_INIT = 0x461C4001u - EPS_BITS;        // bits(T_BEST_INIT) - EPS_BITS
+__device__ __forceinline__ uint32_t t_key(float t) { return __float_as_uint(t) - EPS_BITS; }
+__device__ __forceinline__ float t_of_key(uint32_t k) { return __uint_as_float(k + EPS_BITS); }
+#ifndef PT_UPD
+#define PT_UPD 1
+#endif
+#ifndef PT_REGEN
+#define PT_REGEN 2
+#endif
+__device__ __forceinline__ void closer(bool also, float t, int id, uint32_t& tb, int& ib) {
+    const uint32_t k = t_key(t);
+#if PT_UPD == 1
+    if (also && k < tb) { asm volatile(""); tb = k; ib = id; }
+#else
+    if (also && k < tb) { tb = k; ib = id; }
+#endif
+}
 
 // Primitive id stored as float bits.  The argument is taken BY VALUE on purpose: hipcc 7.2 reads
 // element 0 of the vector when __builtin_bit_cast is applied directly to an ext_vector element
@@ -137,7 +161,7 @@ constexpr float T_BEST_INIT = 10000.0009765625f;
 __device__ __forceinline__ int as_id(float f) { return (int)__float_as_uint(f); }
 
 template <bool COUNT>
-__device__ __forceinline__ void sphere_test(const f4v s, int i, V3 o, V3 d, float& tbest, int& ibest, uint32_t& n_roots) {
+__device__ __forceinline__ void sphere_test(const f4v s, int i, V3 o, V3 d, uint32_t& tb, int& ibest, uint32_t& n_roots) {
     // intersectSphere, raytracer_kernel.cu:44-78.  Most rays miss most spheres: the root block is
     // skipped by the whole wave when no lane has a real root (a branch-free form measured 10 %
     // slower on the Cornell box and 2x slower on 4096 spheres, profiles/r1_variants.json).
@@ -150,17 +174,17 @@ __device__ __forceinline__ void sphere_test(const f4v s, int i, V3 o, V3 d, floa
         const float sq = fsqrt(disc);
         const float r0 = -half_b - sq, r1 = sq - half_b;
         const float root = r0 >= RAY_MIN_T ? r0 : r1;  // r0 > 1e4 fails `< tbest` below, as r1 > r0 would
-        if (root >= RAY_MIN_T && root < tbest) { tbest = root; ibest = i; }
+        closer(true, root, i, tb, ibest);
     }
 }
 
 // intersectPlane, raytracer_kernel.cu:80-103, general plane: pn = (unit normal, -(p.n));
 // dot(p - o, n) is expanded to p.n - o.n, so t = -(o.n + w) / (n.d).
-__device__ __forceinline__ void plane_test(const f4v pn, int id, V3 o, V3 d, float& tbest, int& ibest) {
+__device__ __forceinline__ void plane_test(const f4v pn, int id, V3 o, V3 d, uint32_t& tb, int& ibest) {
     const float denom = pn.x * d.x + pn.y * d.y + pn.z * d.z;
     const float q = fmaf(pn.x, o.x, fmaf(pn.y, o.y, fmaf(pn.z, o.z, pn.w)));
     const float t = q * rcp(-denom);
-    if (fabsf(denom) >= 1e-6f && t >= RAY_MIN_T && t < tbest) { tbest = t; ibest = id; }
+    closer(fabsf(denom) >= 1e-6f, t, id, tb, ibest);
 }
 
 // The same test for planes whose unit normal is +-e_k (every wall of the Cornell boxes): n.d =
@@ -168,16 +192,16 @@ __device__ __forceinline__ void plane_test(const f4v pn, int id, V3 o, V3 d, flo
 // by all such planes of the ray (NaN where the reference rejects |n.d| < 1e-6).  Each axis has its
 // own list (two planes per float4: p_k, bits(id), p_k, bits(id); NaN-padded), so the choice of
 // form is made at upload, not by a branch chain in the loop.
-__device__ __forceinline__ void axis_planes(cf4 list, int n, float o_k, float inv_dk, float& tbest, int& ibest) {
+__device__ __forceinline__ void axis_planes(cf4 list, int n, float o_k, float inv_dk, uint32_t& tb, int& ibest) {
     for (int i = 0; i < n; i += 2) {
         const f4v e = list[i >> 1];
         const float t0 = (e.x - o_k) * inv_dk, t1 = (e.z - o_k) * inv_dk;
-        if (t0 >= RAY_MIN_T && t0 < tbest) { tbest = t0; ibest = as_id(e.y); }
-        if (t1 >= RAY_MIN_T && t1 < tbest) { tbest = t1; ibest = as_id(e.w); }
+        closer(true, t0, as_id(e.y), tb, ibest);
+        closer(true, t1, as_id(e.w), tb, ibest);
     }
 }
 
-__device__ __forceinline__ void tri_test(const f4v r0, const f4v r1, const f4v r2, int id, V3 o, V3 d, float& tbest, int& ibest) {
+__device__ __forceinline__ void tri_test(const f4v r0, const f4v r1, const f4v r2, int id, V3 o, V3 d, uint32_t& tb, int& ibest) {
     // intersectTriangle (raytracer_kernel.cu:106-150) computes Moller-Trumbore's (t, u, v) from
     // the vertices on every test.  The same three numbers come out of an affine map fixed per
     // triangle (rows r0, r1, r2 = inverse of [e1 e2 n], translated by v0; built at upload in
@@ -188,17 +212,16 @@ __device__ __forceinline__ void tri_test(const f4v r0, const f4v r1, const f4v r
     const V3 h = v3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
     const float u = fmaf(r0.x, h.x, fmaf(r0.y, h.y, fmaf(r0.z, h.z, r0.w)));
     const float v = fmaf(r1.x, h.x, fmaf(r1.y, h.y, fmaf(r1.z, h.z, r1.w)));
-    const bool ok = u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t >= RAY_MIN_T && t < tbest;
-    if (ok) { tbest = t; ibest = id; }
+    closer(u >= 0.0f && v >= 0.0f && u + v <= 1.0f, t, id, tb, ibest);
 }
 
 // Closest hit over spheres, planes, triangles in that order with a strict '<'
 // (intersectScene, raytracer_kernel.cu:152-184).  Only (t, primitive id) are tracked; the hit
 // record is built once for the winner.
 template <bool COUNT>
-__device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, float& tbest, int& ibest,
+__device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, float& t_out, int& ibest,
                                             uint32_t& n_roots) {
-    tbest = T_BEST_INIT;
+    uint32_t tbest = TB_INIT;  // biased, see closer()
     ibest = -1;
     const cf4 sph = as_const(sc.sph), pl = as_const(sc.pl), tri = as_const(sc.tri);
     const float qnan = __builtin_nanf("");
@@ -229,6 +252,7 @@ __device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, flo
         tri_test(a0, a1, a2, sc.ns + sc.np + i, o, d, tbest, ibest);
         if (i + 1 < sc.nt) tri_test(b0, b1, b2, sc.ns + sc.np + i + 1, o, d, tbest, ibest);
     }
+    t_out = t_of_key(tbest);
 }
 
 // ---- lane-parallel closest hit --------------------------------------------------------------
@@ -275,7 +299,7 @@ __device__ __forceinline__ void closest_hit_few(const DevSceneF& sc, const FewLd
         rays &= rays - 1ull;
         const V3 O = v3(readlane_f(o.x, L), readlane_f(o.y, L), readlane_f(o.z, L));
         const V3 D = v3(readlane_f(d.x, L), readlane_f(d.y, L), readlane_f(d.z, L));
-        float tb = T_BEST_INIT;
+        uint32_t tb = TB_INIT;  // biased (closer()); valid keys order like the floats they stand for
         int ib = -1;
         // the first 64 of each kind from LDS (re-read per ray: keeping them in registers across the
         // main loop costs a wave of occupancy), the rest from global memory
@@ -290,8 +314,9 @@ __device__ __forceinline__ void closest_hit_few(const DevSceneF& sc, const FewLd
         for (int i = 64 + lane; i - lane < sc.nt; i += 64)
             if (i < sc.nt)
                 tri_test(to_f4v(sc.tri[3 * i]), to_f4v(sc.tri[3 * i + 1]), to_f4v(sc.tri[3 * i + 2]), sc.ns + sc.np + i, O, D, tb, ib);
-        const float tmin = wave_min(tb);  // tb is never NaN: every test stores only values that passed `<`
-        const int winner = __builtin_ctzll(__ballot(tb == tmin));
+        const float tl = t_of_key(tb);
+        const float tmin = wave_min(tl);  // never NaN: every test stores only values that passed `<`
+        const int winner = __builtin_ctzll(__ballot(tl == tmin));
         const int idw = __builtin_amdgcn_readlane(ib, winner);
         if (lane == L) { t_out = tmin; id_out = idw; }
     }
@@ -363,7 +388,12 @@ __device__ __forceinline__ const PT_CONST KArgs* cold() {
 #ifndef PT_NEE_WAVES
 #define PT_NEE_WAVES 6
 #endif
-#define PT_WAVES_PER_EU ((NEE && !COUNT) ? PT_NEE_WAVES : 1)
+// (the plain build with the lane-parallel mode needs 73 VGPRs, one over the step to 7 waves/SIMD; asked for 7 it
+//  fits 72 by spilling 31 SGPRs and runs 9 % slower than at 6 waves/SIMD: left alone)
+#ifndef PT_FEW_WAVES
+#define PT_FEW_WAVES 1
+#endif
+#define PT_WAVES_PER_EU ((NEE && !COUNT) ? PT_NEE_WAVES : ((FEW && !COUNT) ? PT_FEW_WAVES : 1))
 // Threads per workgroup of the path kernel.  One wave per workgroup: the waves of a launch share nothing
 // but the 5-KB LDS image of the scene, and a wave's slot is free for the next launch the moment it ends
 // instead of when the slowest of four does (measured against 256: +2.5 % at 720p / 1 spp with three frames
@@ -397,9 +427,21 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
     __syncthreads();
 
     // lane state
+#if PT_REGEN == 2
+    // The lane's CURRENT pixel (sum, prev, samples still to finish) and its NEXT camera ray, prepared ahead of time
+    // (see the prepare step at the end of the loop body).
+    bool cur_valid = false;          // owns a pixel whose sum is not flushed yet
+    uint32_t pixel = 0, cur_left = 0;
+    bool nx_valid = false;           // a prepared ray is waiting
+    uint32_t nx_pxy = 0;             // pixel of the prepared ray: x | y << 16
+    uint32_t nx_si = 0xFFFFFFFFu;    // samples of that pixel generated so far (>= count: the lane needs a new pixel)
+    uint32_t nx_key = 0;
+    V3 nx_d = v3(0, 0, 1);
+#else
     int my = -1;             // pool index of the pixel this lane owns, -1 = none
     uint32_t pixel = 0, px = 0, py = 0, pixkey = 0;
     uint32_t sample_i = 0;   // samples of `pixel` started so far
+#endif
     bool alive = false;      // a path is in flight
     V3 sum = v3(0, 0, 0);    // radiance sum of this pixel in this launch
     float4 prev = make_float4(0, 0, 0, 0);  // the pixel's accumulator, fetched when the pixel is taken
@@ -620,10 +662,154 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
                     if (!(NEE && shadow) && depth >= a.max_depth) end_path = true;
                 }
             }
+#if PT_REGEN == 2
+            if (end_path) { sum = sum + L; alive = false; cur_left--; }
+#else
             if (end_path) { sum = sum + L; alive = false; }
+#endif
         }
         PT_SECTION(_shade)
         }
+#if PT_REGEN == 2
+        // ---- Regeneration, double-buffered.  A lane whose path ended wants a flush (rarely), and a new camera ray
+        // (always): ~150 instructions that used to run on every trip at the 10-15 % of the lanes that had just
+        // ended.  Now every lane holds its NEXT camera ray ready, so a path end costs a handful of moves (steps 1
+        // and 3), and the expensive part -- pulling pixels from the pool and generating camera rays (step 2) --
+        // runs for all lanes whose next ray is missing at once, when a.regen_min of them have gathered (or when a
+        // lane would otherwise sit idle).  Nobody waits for the batch, so unlike a thresholded regeneration it costs
+        // no idle lane-trips.  Samples of a pixel are still traced one after the other by one lane, in order: the
+        // sums are bit-identical to the single-buffered loop's.
+        const uint64_t dead_mask = __ballot(!alive);
+        if (dead_mask != 0ull) {
+        const PT_CONST KArgs* kc = cold();
+        // ---- (1) a pixel whose last sample just ended is flushed: one 16-B store (its 16-B load was issued when the
+        //          pixel was taken, so the latency is long gone)
+        if (!alive && cur_valid && cur_left == 0u) {
+            float4 acc;
+            if (a.acc_mode == 0u) {  // PT_ACC_SUM
+                acc = make_float4(prev.x + sum.x, prev.y + sum.y, prev.z + sum.z, prev.w + (float)a.count);
+            } else {  // PT_ACC_RUNNING_MEAN, renderKernel :297-304 (count == 1, s0 = frame_count)
+                acc = make_float4(sum.x, sum.y, sum.z, 1.0f);
+                if (a.s0 > 0u) {
+                    const float t = kc->a.mean_t;
+                    acc.x = sum.x * t + prev.x * (1.0f - t);
+                    acc.y = sum.y * t + prev.y * (1.0f - t);
+                    acc.z = sum.z * t + prev.z * (1.0f - t);
+                }
+            }
+            a.accum[pixel] = acc;
+            uint32_t* const rgba = kc->a.rgba;
+            if (rgba) {  // fused convertToRGBAKernel (launches that overlap others display in a pass of their own)
+                // every pixel normally holds the same count: its reciprocal comes from the host (same IEEE divide)
+                const float inv = (a.acc_mode != 0u) ? 1.0f : (acc.w == kc->a.total_w ? kc->a.inv_total_w : 1.0f / acc.w);
+                rgba[pixel] = pack_rgba8_cuda(acc.x * inv, acc.y * inv, acc.z * inv);
+            }
+            cur_valid = false;
+        }
+        // ---- (2) prepare next rays, in a batch
+        // A lane wants one while it has none and either its pixel has samples left to generate or pixels remain.
+        // Taking the NEXT PIXEL ahead of time withholds it from lanes that may fall idle at the end of the frame,
+        // so a lane that still traces does that only in launches with many pixels per lane (a.prefetch_pixels).
+        const bool want_next = !nx_valid && (nx_si < a.count || (!exhausted && (!alive || a.prefetch_pixels != 0u)));
+        const uint32_t n_want = (uint32_t)__popcll(__ballot(want_next));
+        const uint32_t n_idle = (uint32_t)__popcll(__ballot(!alive && want_next));  // lanes that sit idle until prepared
+        if (n_want >= a.regen_min || n_idle >= a.idle_min || (n_idle != 0u && dead_mask == ~0ull)) {
+            // ---- (2a) lanes that have generated every sample of their pixel pull the next pixel from the wave's
+            //           pool; an empty pool is refilled with one ticket from the global counter
+            const bool want = want_next && nx_si >= a.count;
+            const uint64_t pull_mask = __ballot(want);
+            if (pull_mask != 0ull && !exhausted) {
+                if (pool_next >= pool_size) {
+                    const uint32_t need = max(a.units_per_grab, ((uint32_t)__popcll(pull_mask) + 15u) >> 4);
+                    uint32_t ticket = 0;
+                    if (lane == 0) ticket = atomicAdd(a.work_counter + shard * 32u, need);
+                    ticket = __builtin_amdgcn_readfirstlane(ticket);
+                    if (ticket >= shard_units) {
+                        exhausted = true;
+#ifdef PT_TRACE
+                        tr_exh = wall_clock64();
+#endif
+                    } else {
+                        unit0 = ticket;
+                        pool_size = min(need, shard_units - ticket) * 16u;
+                        pool_next = 0;
+                    }
+                }
+                if (!exhausted) {
+                    const uint32_t cand = pool_next + lane_prefix(pull_mask);
+                    if (want && cand < pool_size) {
+                        const uint32_t unit = unit0 + (cand >> 4), li = cand & 15u, q = unit & 3u;
+                        const uint32_t tile = (unit >> 2) * 8u + shard;
+                        // tile / tiles_x without the 25-instruction integer division: float quotient + one fix-up
+                        uint32_t ty = (uint32_t)(((float)tile + 0.5f) * a.inv_tiles_x);
+                        int tx = (int)(tile - ty * a.tiles_x);
+                        if (tx < 0) { tx += (int)a.tiles_x; ty--; }
+                        if (tx >= (int)a.tiles_x) { tx -= (int)a.tiles_x; ty++; }
+                        const uint32_t px = (uint32_t)tx * 8u + (q & 1u) * 4u + (li & 3u);
+                        const uint32_t py = ty * 8u + (q >> 1) * 4u + (li >> 2);
+                        if (px < a.width && py < a.height) {
+                            nx_pxy = px | (py << 16);
+                            nx_si = 0u;
+                        }
+                    }
+                    pool_next = min(pool_next + (uint32_t)__popcll(pull_mask), pool_size);
+                }
+            }
+            // ---- (2b) the camera ray of the pixel's next sample
+            if (want_next && nx_si < a.count) {
+                const uint32_t pixkey = pt_hash(a.seed_hash + ((nx_pxy >> 16) * a.width + (nx_pxy & 0xFFFFu)));
+                nx_key = pt_hash(pixkey + (a.s0 + nx_si));
+                nx_si++;
+                // renderKernel :286-291 + generateCameraRay :245-265:
+                //   (2*(x + xi)/W - 1) * half_w  ==  (x + xi) * (2*half_w/W) - half_w
+                const PT_CONST DevCamF& cam = kc->cam;
+                const float xo = ((float)(nx_pxy & 0xFFFFu) + uni(pt_draw(nx_key, 0, 0))) * cam.sx - cam.half_w;
+                const float yo = ((float)(nx_pxy >> 16) + uni(pt_draw(nx_key, 0, 1))) * cam.sy - cam.half_h;
+                nx_d = v3(cam.fx + cam.rx * xo + cam.ux * yo, cam.fy + cam.ry * xo + cam.uy * yo, cam.fz + cam.rz * xo + cam.uz * yo);
+                if (!(cam.lens_radius > 0.0f)) nx_d = normalized(nx_d);  // (with a lens the direction is finished in step 3)
+                nx_valid = true;
+                if (COUNT) c_samples++;
+            }
+        }
+        // ---- (3) lanes without a path take their prepared ray; the first ray of a pixel also takes the pixel
+        if (!alive && nx_valid) {
+            const PT_CONST DevCamF& cam = kc->cam;
+            if (!cur_valid) {
+                pixel = (nx_pxy >> 16) * a.width + (nx_pxy & 0xFFFFu);
+                if (need_prev) prev = a.accum[pixel];
+                sum = v3(0, 0, 0);
+                cur_left = a.count;
+                cur_valid = true;
+            }
+            key = nx_key;
+            o = v3(cam.ox, cam.oy, cam.oz);
+            d = nx_d;
+            const float lens_radius = cam.lens_radius;
+            if (lens_radius > 0.0f) {  // wave-uniform
+                // Depth of field, Camera_t::getRayDevice (Camera.cu:31-47): the virtual screen is at focus_dist
+                // (Camera.cu:15-19), the origin moves on the lens disk (randomInUnitDisk, :25-29) in the
+                // camera's right/up plane and the ray aims at the point the pinhole ray reaches on that screen.
+                const float r = fsqrt(uni(pt_draw(key, 0, 2))) * lens_radius;
+                const float th = uni(pt_draw(key, 0, 3));
+                const float lx = r * cos2pi(th), ly = r * sin2pi(th);
+                const V3 org = v3(o.x + cam.rx * lx + cam.ux * ly, o.y + cam.ry * lx + cam.uy * ly, o.z + cam.rz * lx + cam.uz * ly);
+                const float fd = cam.focus_dist;
+                d = normalized(v3(o.x + d.x * fd - org.x, o.y + d.y * fd - org.y, o.z + d.z * fd - org.z));
+                o = org;
+            }
+            beta = v3(1, 1, 1);
+            L = v3(0, 0, 0);
+            depth = 0;
+            alive = true;
+            nx_valid = false;
+            if (NEE) { shadow = false; prev_pdf_b = -1.0f; }
+        }
+        }  // some lane has no path
+        PT_SECTION(_regen)
+        // done when nothing is in flight, prepared or unflushed, and the frame is exhausted
+        if (__ballot(alive || nx_valid || cur_valid) == 0ull && exhausted) break;
+    }
+#else
         // Steps (1)-(3) run at the few lanes whose path just ended; executed on every trip they
         // cost as many instructions as a third of an intersection at ~15 % lane occupancy.  They
         // are therefore entered only when a.regen_min lanes have something to do there (or no
@@ -740,6 +926,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
         // some lane flushes / pulls on the next trip
         if (__ballot(alive) == 0ull && __ballot(my >= 0) == 0ull && exhausted) break;
     }
+#endif
 
 #ifdef PT_TRACE
     if (a.trace && lane == 0) {

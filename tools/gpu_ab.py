@@ -31,6 +31,13 @@ g, gc = scenes.glass_stress(1280, 720)
 timeit("glass_16spp", g, gc, abi.render_params(max_depth=32), 16, 10)
 rs, rc = scenes.random4096(1280, 720)
 timeit("rand4096_720p_1spp", rs, rc, abi.render_params(max_depth=16), 1, 3, warm=1)
+# bit-identity check between builds: md5 of small accumulation buffers (same samples, same launch shape)
+import hashlib
+for nm, (s_, c_), dep in (("md5_cornell", scenes.cuda_default(160, 90), 50), ("md5_glass", scenes.glass_stress(96, 54), 32), ("md5_rand4096", scenes.random4096(64, 36), 16)):
+    for fl in (0, abi.FLAG_NEE_MIS):
+        r.set_scene(s_); r.set_camera(c_); r.reset()
+        r.render(0, 4, abi.render_params(max_depth=dep, flags=fl))
+        out[nm + ("_mis" if fl else "")] = hashlib.md5(r.accum().tobytes()).hexdigest()[:8]
 print(json.dumps(out))
 ''' % ROOT
 res = {}
@@ -41,6 +48,8 @@ for v in sys.argv[1:]:
         elif kv.startswith("flight="): env["PT_FLIGHT"] = kv.split("=")[1]
         elif kv.startswith("few="): env["PT_AMD_FEW_MAX"] = kv.split("=")[1]
         elif kv.startswith("regen="): env["PT_AMD_REGEN_MIN"] = kv.split("=")[1]
+        elif kv.startswith("idle="): env["PT_AMD_IDLE_MIN"] = kv.split("=")[1]
+        elif kv.startswith("prefetch="): env["PT_AMD_PREFETCH"] = kv.split("=")[1]
         elif kv.startswith("queues="): env["GPU_MAX_HW_QUEUES"] = kv.split("=")[1]
         elif kv != "main": env["PT_AMD_LIB"] = os.path.join(ROOT, "path_tracer_amd", "lib", f"libpt_amd_{kv}.so")
     p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=280)
