@@ -241,29 +241,29 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
 int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32_t height,
                       uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* params);
 /* Frames in flight (1..8, default 1).  With n > 1, consecutive PT_ACC_SUM path
- * launches go round-robin to n internal streams, each with an accumulator of
- * its own, so launch k+1 fills the compute units that launch k leaves idle
- * while its last long paths finish (the reference's frame loop,
- * main.cu:284-303, serialises launch and display; there is no counterpart).
- * The sums are folded into the context's accumulation buffer, in a fixed order,
- * by pt_flush() and by every call that reads or replaces that buffer
+ * launches go round-robin to n internal streams, so launch k+1 fills the compute
+ * units that launch k leaves idle while its last long paths finish (the
+ * reference's frame loop, main.cu:284-303, serialises launch and display; there is
+ * no counterpart).  Each such launch writes its own sums into a buffer of its
+ * chain, and a fold pass behind it adds them to the accumulation buffer (and, with
+ * fused_rgba8, makes the display from the new sums).  The fold passes run in launch
+ * order, so the buffer receives acc += launch k for k = 0, 1, 2, ... exactly as
+ * under serial launches: the image is bit-identical to the n = 1 image, and the
+ * display behind launch k is the mean of samples 0..k as in the reference's loop.
+ * Every call that reads or replaces the accumulation buffer first waits (on the
+ * context's stream, not on the host) for the fold passes still queued
  * (pt_resolve, pt_readback*, pt_upload_accum, pt_reset, pt_sync, pt_counters,
- * pt_bind_accum, pt_set_stream, pt_upload_scene, pt_resize); a caller that
- * reads pt_accum_device_ptr() or a bound buffer itself calls pt_flush() first,
- * which is asynchronous on the context's stream.  The image is reproducible
- * run to run; it differs from the n = 1 image only by float summation order.
- * A fused display (fused_rgba8) is then made by a pass of its own behind each
- * launch; written while other launches are in flight it shows, per pixel, a
- * mean that may or may not include their newest sample.  Folding the chains
- * redoes it from the folded sums, so a display read through the library is exact.
+ * pt_bind_accum, pt_set_stream, pt_upload_scene, pt_resize); a caller that reads
+ * pt_accum_device_ptr() or a bound buffer itself calls pt_flush() first, which is
+ * asynchronous on the context's stream.
  * n > 3 needs more hardware queues than HIP's default of 4 per process:
  * GPU_MAX_HW_QUEUES >= n + 4 in the environment before HIP initialises (16 for
  * n = 8).  Chains that share a queue serialise (with the default, 4 chains are
  * slower than 3), so the request is GRANTED only up to what the variable, as
  * the library finds it at pt_create, leaves room for: 3 chains when it is unset
  * or <= 7, GPU_MAX_HW_QUEUES - 4 beyond that.  The call still returns PT_OK;
- * pt_frames_in_flight() returns the number in effect.  Memory: one more
- * accumulation buffer per chain beyond the first.
+ * pt_frames_in_flight() returns the number in effect.  Memory: one buffer of the
+ * frame's size (16 B per pixel) per chain.
  *
  * Large calls.  A pixel belongs to one lane per launch, so one long launch over
  * few pixels per lane (2.3 at 1280x720) ends with most lanes idle.  On frames
@@ -272,9 +272,10 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
  * than 48 samples join the open burst; with n = 1, a call for 12 samples or
  * more is a burst of its own on three chains (GPU_MAX_HW_QUEUES - 4 of them
  * when the environment grants more, up to 8), folded (and, with fused_rgba8,
- * resolved) before pt_render returns, so nothing stays in flight.  The partition
+ * displayed) before pt_render returns, so nothing stays in flight.  The partition
  * depends only on the call's arguments: the image is reproducible and equals
- * the single launch's up to float summation order.  (Environment variable
+ * the single launch's up to float summation order (the launches' sums are added
+ * one after the other instead of sample by sample).  (Environment variable
  * PT_AMD_CHUNK=0, read at pt_create, keeps every call one launch.) */
 int pt_set_frames_in_flight(PtContext* ctx, uint32_t n);
 uint32_t pt_frames_in_flight(PtContext* ctx);

@@ -84,10 +84,14 @@ struct PtContext {
     hipStream_t chain_stream[PT_MAX_CHAINS] = {};
     hipEvent_t chain_done[PT_MAX_CHAINS] = {};
     hipEvent_t fork_event = nullptr;
-    float4* chain_acc[PT_MAX_CHAINS] = {};  // [0] unused (= accum)
+    float4* chain_acc[PT_MAX_CHAINS] = {};  // per chain: the sums of the chain's launch in flight (written whole by it, folded
+                                            // into the accumulation buffer by the pass behind it)
     size_t chain_acc_pixels = 0;
+    hipEvent_t fold_done[PT_MAX_CHAINS] = {};  // per chain: the fold pass behind its last launch (and, through the chain of
+                                               // waits, every earlier fold pass of the burst) is done
+    bool display_current = false;           // the display buffer holds the mean of everything folded so far
     uint32_t burst = 0;                // launches since the chains were last joined
-    bool burst_displayed = false;      // some launch of the burst made a display pass
+    bool burst_displayed = false;      // some launch of the burst asked for a display
     uint32_t compute_units = 256;
     uint32_t burst_chains = 3;         // most chains worth running at once: 3 on HIP's default 4 hardware queues, else
                                        // GPU_MAX_HW_QUEUES - 4 (up to 8); the cap of pt_set_frames_in_flight and the
@@ -147,29 +151,19 @@ int alloc_frame(PtContext* ctx, uint32_t w, uint32_t h) {
 
 constexpr size_t WORK_SET_WORDS = 256;  // 8 shards x 32 words (128 B apart)
 
-ChainAccs chain_accs(const PtContext* ctx, uint32_t n) {
-    ChainAccs c{};
-    c.acc[0] = ctx->accum;
-    for (uint32_t k = 1; k < n; ++k) c.acc[k] = ctx->chain_acc[k];
-    c.n = n;
-    return c;
-}
-
-// Frames in flight: makes the context's stream wait for every chain and folds the chains'
-// accumulators into the context's.  A no-op when no burst is open.
+// Frames in flight: makes the context's stream wait for the last fold pass (each waits for the one before it, so
+// that one is behind all others).  A no-op when no burst is open.  Nothing is left to add up: every
+// launch's sums are already in the accumulation buffer, in launch order.
 int join_chains(PtContext* ctx) {
     if (ctx->burst == 0) return PT_OK;
-    const uint32_t used = ctx->burst < ctx->flight ? ctx->burst : ctx->flight;
-    for (uint32_t c = 0; c < used; ++c) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->chain_done[c], 0));
-    if (used > 1) {
-        HIP_TRY(pt_launch_merge(chain_accs(ctx, used), ctx->width * ctx->height, ctx->stream));
-    }
+    const uint32_t last = (ctx->burst - 1u) % ctx->flight;
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->fold_done[last], 0));
     ctx->burst = 0;
-    if (ctx->burst_displayed) {
-        // the display passes of the burst were previews; the folded sums give the exact image
-        ctx->burst_displayed = false;
+    if (ctx->burst_displayed && !ctx->display_current) {
+        // some launch of the burst asked for a display and a later one did not: redo it from the sums
         HIP_TRY(pt_launch_resolve(ctx->accum, ctx->display, ctx->width * ctx->height, PT_ACC_SUM, PT_RESOLVE_RGBA8_CUDA, ctx->stream));
     }
+    ctx->burst_displayed = false;
     return PT_OK;
 }
 
@@ -185,7 +179,7 @@ int switch_stream(PtContext* ctx, hipStream_t to) {
     return PT_OK;
 }
 
-// Streams, events and accumulators of chains 1..flight-1 for the current frame size (zeroed).
+// Streams, events and buffers of the chains for the current frame size.
 int prepare_chains(PtContext* ctx) {
     const size_t npix = (size_t)ctx->width * ctx->height;
     if (!ctx->fork_event) HIP_TRY(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
@@ -195,17 +189,15 @@ int prepare_chains(PtContext* ctx) {
     for (uint32_t c = 0; c < ctx->flight; ++c) {
         if (!ctx->chain_stream[c]) HIP_TRY(hipStreamCreateWithFlags(&ctx->chain_stream[c], hipStreamNonBlocking));
         if (!ctx->chain_done[c]) HIP_TRY(hipEventCreateWithFlags(&ctx->chain_done[c], hipEventDisableTiming));
+        if (!ctx->fold_done[c]) HIP_TRY(hipEventCreateWithFlags(&ctx->fold_done[c], hipEventDisableTiming));
     }
     if (ctx->chain_acc_pixels != npix) {
-        for (uint32_t c = 1; c < PT_MAX_CHAINS; ++c)
+        for (uint32_t c = 0; c < PT_MAX_CHAINS; ++c)
             if (ctx->chain_acc[c]) { HIP_TRY(hipFree(ctx->chain_acc[c])); ctx->chain_acc[c] = nullptr; }
         ctx->chain_acc_pixels = npix;
     }
-    for (uint32_t c = 1; c < ctx->flight; ++c)
-        if (!ctx->chain_acc[c]) {
-            HIP_TRY(hipMalloc((void**)&ctx->chain_acc[c], npix * sizeof(float4)));
-            HIP_TRY(hipMemsetAsync(ctx->chain_acc[c], 0, npix * sizeof(float4), ctx->stream));  // ordered before the fork event
-        }
+    for (uint32_t c = 0; c < ctx->flight; ++c)
+        if (!ctx->chain_acc[c]) HIP_TRY(hipMalloc((void**)&ctx->chain_acc[c], npix * sizeof(float4)));  // written whole by every launch
     return PT_OK;
 }
 
@@ -316,15 +308,17 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
         }
         chain = ctx->burst % ctx->flight;
         stream = ctx->chain_stream[chain];
+        // (a chain's launches and fold passes alternate on its stream: its buffer is folded before it is written again)
         if (ctx->burst < ctx->flight) HIP_TRY(hipStreamWaitEvent(stream, ctx->fork_event, 0));  // first launch of this chain in the burst
     } else {
         if (int rc = join_chains(ctx)) return rc;
     }
     PathArgs a{};
-    a.accum = noalloc ? into : (chain == 0 ? ctx->accum : ctx->chain_acc[chain]);
-    // a launch that overlaps others displays in a pass of its own behind it (pt_display_kernel): the mean over all chains
-    const bool display_pass = pipelined && prm->fused_rgba8;
-    a.rgba = (prm->fused_rgba8 && !display_pass) ? (uint32_t*)ctx->display : nullptr;
+    // A launch that overlaps others writes its own sums (sum_r, sum_g, sum_b, count) whole into its chain's buffer;
+    // the fold pass behind it adds them to the accumulation buffer and makes the display (pt_fold_kernel).
+    a.accum = noalloc ? into : (pipelined ? ctx->chain_acc[chain] : ctx->accum);
+    a.overwrite = pipelined ? 1u : 0u;
+    a.rgba = (prm->fused_rgba8 && !pipelined) ? (uint32_t*)ctx->display : nullptr;
     a.counters = (prm->flags & PT_FLAG_COUNTERS) ? ctx->counters : nullptr;
     a.s0 = sample_begin; a.count = sample_count;
     a.max_depth = prm->max_depth; a.rr_depth = prm->rr_depth; a.seed_hash = hash32(prm->seed);
@@ -432,11 +426,16 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
         a.trace = ctx->trace;
     } else a.trace = nullptr;
     HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, few, blocks, stream));
-    if (display_pass) ctx->burst_displayed = true;
-    if (display_pass)
-        HIP_TRY(pt_launch_display(chain_accs(ctx, ctx->flight), (uint32_t*)ctx->display, ctx->width * ctx->height, stream));
     if (pipelined) {
-        HIP_TRY(hipEventRecord(ctx->chain_done[chain], stream));
+        // The fold pass runs behind the launch on the chain's own stream (no stream of its own: HIP's default is 4
+        // hardware queues per process, and streams that share one serialise) and after the fold pass of the launch
+        // before it, whichever chain that ran on: the accumulation buffer receives the launches in launch order.
+        if (ctx->burst > 0) HIP_TRY(hipStreamWaitEvent(stream, ctx->fold_done[(ctx->burst - 1u) % ctx->flight], 0));
+        HIP_TRY(pt_launch_fold(ctx->accum, ctx->chain_acc[chain], prm->fused_rgba8 ? (uint32_t*)ctx->display : nullptr,
+                               ctx->width * ctx->height, stream));
+        HIP_TRY(hipEventRecord(ctx->fold_done[chain], stream));
+        if (prm->fused_rgba8) ctx->burst_displayed = true;
+        ctx->display_current = prm->fused_rgba8 != 0;
         ctx->burst++;
     }
     if (trace_file) {
@@ -511,6 +510,7 @@ int pt_destroy(PtContext* ctx) {
     for (uint32_t c = 0; c < PT_MAX_CHAINS; ++c) {
         if (c > 0 && ctx->chain_stream[c]) { (void)hipStreamSynchronize(ctx->chain_stream[c]); (void)hipStreamDestroy(ctx->chain_stream[c]); }
         if (ctx->chain_done[c]) (void)hipEventDestroy(ctx->chain_done[c]);
+        if (ctx->fold_done[c]) (void)hipEventDestroy(ctx->fold_done[c]);
         if (ctx->chain_acc[c]) (void)hipFree(ctx->chain_acc[c]);
     }
     if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);

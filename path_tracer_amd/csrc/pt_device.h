@@ -55,6 +55,7 @@ struct PathArgs {
     uint32_t max_depth, rr_depth, seed_hash;
     uint32_t light_colour;   // PT_FLAG_LIGHT_COLOUR
     uint32_t acc_mode;       // PT_ACC_*
+    uint32_t overwrite;      // != 0 (PT_ACC_SUM only): the buffer receives this launch's (sums, count), not buffer + them
     float mean_t;            // 1/(s0+1) for PT_ACC_RUNNING_MEAN
     uint32_t tiles_x, tiles_y;  // 8x8 pixel tiles
     float inv_tiles_x;
@@ -105,14 +106,10 @@ hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArg
 hipError_t pt_path_resident_blocks(bool nee, bool count, bool few, int device, uint32_t* blocks);
 hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint32_t acc_mode, uint32_t mode,
                              hipStream_t stream);
-// frames in flight: the accumulators of the chains of a context ([0] = the context's own / bound buffer), by value
+// frames in flight: adds the sums of one overlapped launch (its chain's buffer) to the accumulation buffer and,
+// with rgba != nullptr, makes the display from the new sums
 constexpr uint32_t PT_MAX_CHAINS = 8;
-struct ChainAccs {
-    float4* acc[PT_MAX_CHAINS];
-    uint32_t n;  // chains in use, 1..PT_MAX_CHAINS
-};
-hipError_t pt_launch_merge(const ChainAccs& chains, uint32_t npix, hipStream_t stream);
-hipError_t pt_launch_display(const ChainAccs& chains, uint32_t* rgba, uint32_t npix, hipStream_t stream);
+hipError_t pt_launch_fold(float4* accum, const float4* launch_sums, uint32_t* rgba, uint32_t npix, hipStream_t stream);
 hipError_t pt_launch_valu_peak(float* sink, uint32_t packed, uint32_t iters, uint32_t blocks, hipStream_t stream);
 hipError_t pt_launch_primary_ids(const DevSceneD& sc, const DevCamD& cam, uint32_t* obj, uint32_t* mat,
                                  hipStream_t stream);

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
     // counters (instrumented build only)
     uint32_t c_samples = 0, c_rays = 0, c_hits = 0, c_roots = 0, c_b0 = 0, c_b1 = 0, c_b2 = 0, c_b3 = 0, c_b4 = 0,
              c_diff = 0, c_nee = 0, c_shadow = 0;
-    const bool need_prev = a.acc_mode == 0u || a.s0 > 0u;
+    const bool need_prev = a.overwrite == 0u && (a.acc_mode == 0u || a.s0 > 0u);
 #ifdef PT_TRACE
     // timeline of this wave (100 MHz constant clock): start, frame exhausted, first lane-parallel trip, end
     uint64_t tr_start = wall_clock64(), tr_exh = 0, tr_few = 0;
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
         //          pixel was taken, so the latency is long gone)
         if (!alive && cur_valid && cur_left == 0u) {
             float4 acc;
-            if (a.acc_mode == 0u) {  // PT_ACC_SUM
+            if (a.acc_mode == 0u) {  // PT_ACC_SUM (prev is zero in a launch that writes its own sums whole)
                 acc = make_float4(prev.x + sum.x, prev.y + sum.y, prev.z + sum.z, prev.w + (float)a.count);
             } else {  // PT_ACC_RUNNING_MEAN, renderKernel :297-304 (count == 1, s0 = frame_count)
                 acc = make_float4(sum.x, sum.y, sum.z, 1.0f);
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
         //          pixel was taken, so its latency is long gone)
         if (!alive && my >= 0 && sample_i == a.count) {
             float4 acc;
-            if (a.acc_mode == 0u) {  // PT_ACC_SUM
+            if (a.acc_mode == 0u) {  // PT_ACC_SUM (prev is zero in a launch that writes its own sums whole)
                 acc = make_float4(prev.x + sum.x, prev.y + sum.y, prev.z + sum.z, prev.w + (float)a.count);
             } else {  // PT_ACC_RUNNING_MEAN, renderKernel :297-304 (count == 1, s0 = frame_count)
                 acc = make_float4(sum.x, sum.y, sum.z, 1.0f);
@@ -987,36 +987,24 @@ __global__ __launch_bounds__(256) void pt_resolve_kernel(const float4* __restric
 }
 
 // ------------------------------------------------------------------------------------------
-// Frames in flight: folds the chains' accumulators into the first one in a fixed order
-// (acc0 + acc1 + acc2 + ..., so the result is reproducible) and clears the others.
-__global__ __launch_bounds__(256) void pt_merge_kernel(const ChainAccs chains, uint32_t npix) {
+// Frames in flight: the pass behind every overlapped launch.  The launch wrote its own sums whole into its chain's
+// buffer; this adds them to the accumulation buffer and, when asked, makes the display from the new sums
+// (convertToRGBAKernel, Window.cuh:16-30).  The passes of a context run on one stream in launch order, so the
+// buffer grows exactly as under serial launches -- acc += launch k, k = 0, 1, 2, ... -- and the frame shown after
+// launch k is the mean of samples 0..k, as in the reference's frame loop (main.cu:284-303).  HBM-bound: 16 B read +
+// 16 B read + 16 B written (+ 4 B) per pixel, beside path launches that are VALU-bound and leave HBM idle.
+__global__ __launch_bounds__(256) void pt_fold_kernel(float4* __restrict__ accum, const float4* __restrict__ sums,
+                                                      uint32_t* __restrict__ rgba, uint32_t npix) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= npix) return;
-    float4 a = chains.acc[0][p];
-    const float4 zero = make_float4(0, 0, 0, 0);
-    for (uint32_t c = 1; c < chains.n; ++c) {  // wave-uniform trip count; the loads of one lane are independent
-        const float4 q = chains.acc[c][p];
-        a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
-        chains.acc[c][p] = zero;
+    float4 a = accum[p];
+    const float4 q = sums[p];
+    a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+    accum[p] = a;
+    if (rgba) {
+        const float inv = a.w > 0.0f ? 1.0f / a.w : 0.0f;
+        rgba[p] = pack_rgba8_cuda(a.x * inv, a.y * inv, a.z * inv);
     }
-    chains.acc[0][p] = a;
-}
-
-// Frames in flight: the display of a frame, as a pass of its own behind the frame's launch on the chain's
-// stream.  It shows the mean over all chains (their launches may be running: each (sum, n) is read either
-// before or after its 16-B store, a consistent mean either way; display only).  The path launches are VALU-
-// bound and leave HBM idle, so these 68 B per pixel ride along; fused into the path kernel the same reads
-// sit in the regeneration block at low lane occupancy and cost 7 % of the frame rate.
-__global__ __launch_bounds__(256) void pt_display_kernel(const ChainAccs chains, uint32_t* __restrict__ rgba, uint32_t npix) {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= npix) return;
-    float4 a = chains.acc[0][p];
-    for (uint32_t c = 1; c < chains.n; ++c) {
-        const float4 q = chains.acc[c][p];
-        a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
-    }
-    const float inv = a.w > 0.0f ? 1.0f / a.w : 0.0f;
-    rgba[p] = pack_rgba8_cuda(a.x * inv, a.y * inv, a.z * inv);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1096,13 +1084,8 @@ hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint
     return hipGetLastError();
 }
 
-hipError_t pt_launch_merge(const ChainAccs& chains, uint32_t npix, hipStream_t stream) {
-    hipLaunchKernelGGL(pt_merge_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, chains, npix);
-    return hipGetLastError();
-}
-
-hipError_t pt_launch_display(const ChainAccs& chains, uint32_t* rgba, uint32_t npix, hipStream_t stream) {
-    hipLaunchKernelGGL(pt_display_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, chains, rgba, npix);
+hipError_t pt_launch_fold(float4* accum, const float4* launch_sums, uint32_t* rgba, uint32_t npix, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_fold_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, accum, launch_sums, rgba, npix);
     return hipGetLastError();
 }
 

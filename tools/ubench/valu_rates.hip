@@ -64,6 +64,11 @@ __global__ __launch_bounds__(256) void k(uint32_t* sink, uint32_t iters, uint32_
                                            : "+v"(x[c]), "+v"(f[c]), "=&v"(tmp) : "v"(f[(c + 1) & 7]), "v"(fa) : "vcc", "s10", "s11", "scc");
                 if (OP == 40) asm volatile("v_sub_u32 %2, %3, %4\n\tv_min_u32 %5, %2, %1\n\tv_cmp_ne_u32 vcc, %5, %1\n\tv_mov_b32 %1, %5\n\tv_cndmask_b32 %0, %0, %2, vcc"
                                            : "+v"(x[c]), "+v"(f[c]), "=&v"(tmp), "+v"(f[(c + 1) & 7]) : "v"(fa), "v"(tmp2) : "vcc");
+                if (OP == 41) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_add_u32 s12, s12, 1" : "+v"(f[c]) : "v"(fm), "v"(fa) : "s12", "scc");
+                if (OP == 42) asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %3, %3, %1, %2\n\ts_add_u32 s12, s12, 1" : "+v"(f[c]), "+v"(f[(c + 4) & 7]) : "v"(fm), "v"(fa) : "s12", "scc");
+                if (OP == 43) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_add_u32 s12, s12, 1\n\ts_and_b32 s13, s12, 7" : "+v"(f[c]) : "v"(fm), "v"(fa) : "s12", "s13", "scc");
+                if (OP == 44) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_cmp_eq_u32 s12, 12345\n\ts_cbranch_scc1 1f\n1:" : "+v"(f[c]) : "v"(fm), "v"(fa) : "scc");
+                if (OP == 45) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_and_saveexec_b64 s[12:13], exec\n\ts_or_b64 exec, exec, s[12:13]" : "+v"(f[c]) : "v"(fm), "v"(fa) : "s12", "s13", "scc");
                 if (OP == 30) asm volatile("s_and_b64 vcc, vcc, s[10:11]\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[c]) : "v"(m) : "vcc", "scc");
                 if (OP == 31) asm volatile("s_and_b64 s[12:13], vcc, s[10:11]\n\tv_cndmask_b32_e64 %0, %0, %1, s[12:13]" : "+v"(x[c]) : "v"(m) : "s12", "s13", "scc");
                 if (OP == 32) asm volatile("v_cmp_le_f32 vcc, %2, %1\n\tv_cndmask_b32 %4, %3, %1, vcc\n\tv_cmp_lt_f32 vcc, %4, %5\n\tv_cndmask_b32 %0, %0, %6, vcc\n\tv_cndmask_b32 %5, %5, %4, vcc"
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256) void k(uint32_t* sink, uint32_t iters, uint32_
 
 typedef void (*K)(uint32_t*, uint32_t, uint32_t);
 int main(int argc, char** argv) {
-    const int first = argc > 1 ? atoi(argv[1]) : 0, last = argc > 2 ? atoi(argv[2]) : 40;
+    const int first = argc > 1 ? atoi(argv[1]) : 0, last = argc > 2 ? atoi(argv[2]) : 45;
     const char* names[] = {"v_fma_f32", "v_mul_lo_u32", "v_mul_u32_u24", "v_mad_u32_u24", "v_sqrt_f32", "v_rcp_f32", "v_sin_f32", "v_xor_b32",
                            "v_lshrrev_b32", "v_cndmask_b32", "v_mul_hi_u32", "v_cvt_f32_u32", "v_cmp_lt_f32", "v_mad_u64_u32", "v_add_u32",
                            "v_min3_f32", "v_pk_fma_f32", "v_xad_u32", "v_alignbit_b32", "v_lshl_add_u32", "v_cndmask_b32_e64(sgpr pair)",
@@ -89,8 +94,9 @@ int main(int argc, char** argv) {
                            "v_fmac_f32", "v_cmp_lt_u32", "v_and_or_b32", "s_and vcc + cndmask(vcc) (1 VALU)", "s_and sgpr + cndmask_e64 (1 VALU)",
                            "cmp,cndmask,cmp,cndmask,cndmask (5 VALU, no SALU)", "cmp,cndmask,cndmask (3 VALU)", "cmp,s_nop,cndmask (2 VALU)", "cmp,s_and vcc,cndmask (2 VALU)",
                            "update: mov,cmp,cmp,s_and,cndmask,cndmask (current)", "update: mov,sub_u32,cmp_u32,cndmask,cndmask", "update: sub_u32,cmpx,mov,mov (exec)",
-                           "update: sub_u32,cmp_u32,s_and_saveexec,mov,mov", "update: sub,min_u32,cmp_ne,mov,cndmask"};
-    K ks[] = {k<0>, k<1>, k<2>, k<3>, k<4>, k<5>, k<6>, k<7>, k<8>, k<9>, k<10>, k<11>, k<12>, k<13>, k<14>, k<15>, k<16>, k<17>, k<18>, k<19>, k<20>, k<21>, k<22>, k<23>, k<24>, k<25>, k<26>, k<27>, k<28>, k<29>, k<30>, k<31>, k<32>, k<33>, k<34>, k<35>, k<36>, k<37>, k<38>, k<39>, k<40>};
+                           "update: sub_u32,cmp_u32,s_and_saveexec,mov,mov", "update: sub,min_u32,cmp_ne,mov,cndmask",
+                           "fma + 1 salu (1 VALU)", "2 fma + 1 salu (2 VALU)", "fma + 2 salu (1 VALU)", "fma + s_cmp + s_cbranch (1 VALU)", "fma + saveexec + or exec (1 VALU)"};
+    K ks[] = {k<0>, k<1>, k<2>, k<3>, k<4>, k<5>, k<6>, k<7>, k<8>, k<9>, k<10>, k<11>, k<12>, k<13>, k<14>, k<15>, k<16>, k<17>, k<18>, k<19>, k<20>, k<21>, k<22>, k<23>, k<24>, k<25>, k<26>, k<27>, k<28>, k<29>, k<30>, k<31>, k<32>, k<33>, k<34>, k<35>, k<36>, k<37>, k<38>, k<39>, k<40>, k<41>, k<42>, k<43>, k<44>, k<45>};
     uint32_t* sink;
     if (hipMalloc(&sink, 256) != hipSuccess) return 1;
     hipDeviceProp_t p;
@@ -101,7 +107,7 @@ int main(int argc, char** argv) {
     hipEventCreate(&e0); hipEventCreate(&e1);
     double base = 0;
     printf("{\"device\": \"%s\", \"cus\": %d, \"rates\": {", p.name, p.multiProcessorCount);
-    for (int o = first; o <= last && o < 41; ++o) {
+    for (int o = first; o <= last && o < 46; ++o) {
         hipLaunchKernelGGL(ks[o], dim3(blocks), dim3(256), 0, 0, sink, iters / 10, 12345u);
         if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { printf("\"%s\": \"launch failed\"}}\n", names[o]); return 2; }
         hipEventRecord(e0);
