@@ -1,23 +1,30 @@
 """bench.py — Msamples/s of the per-pixel render path on N MI355X (one process per GPU).
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on that fits one
+Headline workload (BASELINE.json configs[1], the configuration the metric is quoted on that fits one
 GPU): the Cornell box of cuda_pathtracer/src/main.cu at 1280x720, progressive rendering at
-1 sample per pixel per frame with the display (RGBA8) resolve fused into every frame.
+1 sample per pixel per frame with the display (RGBA8) made for every frame.
 A "step" is one frame: one launch of the path kernel over all 921 600 pixels.
   N = 1 : K frames on one GPU.
   N > 1 : sample-split, weak scaling — every rank renders K frames of 1 spp for its own
           disjoint sample indices, then the float4 accumulation buffers are summed once with an
-          RCCL reduce to rank 0 (inside the timed region), which resolves the image.
-          `--scaling strong` divides the K steps among the ranks instead (BASELINE config 3, e.g.
-          `--workload cornell_4k_16spp_per_step --steps 64` = 4K at 1024 spp split N ways).
+          RCCL reduce to rank 0 (inside the timed region, also reported on its own as `reduce_ms`),
+          which resolves the image.
+BASELINE's metric is quoted "at 1280x720 & 4K", and north_star's scaling target is defined on
+config 3 (4K at 1024 spp, sample-split with one RCCL reduce), so every run also carries that
+workload as a second leg under `legs`: 3840x2160, 16 spp per step, 64 steps = 1024 spp, the steps
+DIVIDED among the ranks (strong scaling), wall time including the reduce.  At N = 1 it is the
+single-GPU 4K figure the N > 1 runs compare with.  (`--no-4k-leg` leaves it out.)
+
 Scene, camera and accumulation buffer are resident in HBM before the timed region; the
 display buffer is never copied to the host inside it (the reference's per-frame D2H + XPutImage
 is the X11 path, out of scope).
 
 One JSON line on rank 0.  `roofline` prices the path kernel against the FP32 vector peak
 (north_star: "FP32 VALU-bound, not a dense contraction, so no MFMA"): achieved = algorithmic
-FLOPs per launch (event counters x the fixed cost table of SURVEY §8(d)) / average launch
-duration from HIP events on the launch stream.  `cpu_baseline` times the CPU oracle
+FLOPs per launch (event counters x the fixed cost table of SURVEY §8(d)) / time per launch from HIP
+events on the launch stream around the K launches (the overlapped launches fork from and join that
+stream, so this is first start to last end / K, the figure tools/trace_span.py derives from a
+rocprofv3 kernel trace of the same command).  `cpu_baseline` times the CPU oracle
 (oracle/libpt_oracle.so, OpenMP) on a bounded number of frames of the same workload.
 """
 from __future__ import annotations
@@ -41,6 +48,7 @@ WORKLOADS = {
     "glass_stress_720p_16spp_per_step": ("glass_stress", 1280, 720, 16, 32),
     "random4096_4k_1spp_per_step": ("random4096", 3840, 2160, 1, 16),
 }
+LEG_4K = ("cornell_4k_16spp_per_step", 64, 2)  # BASELINE config 3: 64 steps of 16 spp = 1024 spp; 2 warm-up steps
 
 
 def main() -> int:
@@ -55,23 +63,24 @@ def main() -> int:
                     help="consecutive launches overlapped on internal streams (include/pt.h); 1 = strictly serial launches")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
-                    help="weak: every rank renders K steps (default, the driver's contract); strong: the K steps are "
-                         "divided among the ranks (BASELINE config 3: a fixed sample count split across the GPUs)")
+                    help="headline leg only. weak: every rank renders K steps (default, the driver's contract); strong: the K "
+                         "steps are divided among the ranks")
+    ap.add_argument("--no-4k-leg", action="store_true", help="leave out the 4K / 1024 spp strong-scaling leg (BASELINE config 3)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks over gloo, all on GPU 0: exercises the multi-rank code path on a one-GPU box (the "
-                         "number means nothing)")
+                         "numbers mean nothing)")
     args = ap.parse_args()
 
     # frames in flight need one hardware queue per chain plus a few for the launch stream and torch's own;
-    # HIP's default of 4 per process makes chains share a queue (and serialise) from 4 chains on
-    # (8 chains: 6.5 Gsamples/s with 8 queues, 9.3 with 12, 9.5 with 16)
+    # HIP's default of 4 per process makes chains share a queue (and serialise) from 4 chains on, and the library
+    # grants only what the variable leaves room for (pt_set_frames_in_flight): 8 chains with 12 or more
     if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
         os.environ["GPU_MAX_HW_QUEUES"] = "16"
     import torch
     import torch.distributed as dist
 
     from path_tracer_amd import abi, scenes
-    from path_tracer_amd.distributed import progressive_schedule, reduce_accum
+    from path_tracer_amd.distributed import progressive_schedule, reduce_accum, strong_schedule
     from path_tracer_amd.renderer import Renderer, algorithmic_flops
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,29 +105,7 @@ def main() -> int:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    scene_name, W, H, spp, max_depth = WORKLOADS[args.workload]
-    scene, cam = scenes.builtin(scene_name, W, H)
-    flags = abi.FLAG_NEE_MIS if args.mis else 0
-    params = abi.render_params(max_depth=max_depth, flags=flags, fused_rgba8=1, pixels_per_wave=args.pixels_per_wave)
-
     stage("process group up")
-    r = Renderer(local_rank)
-    r.use_torch_stream()
-    r.set_scene(scene)
-    r.set_camera(cam)
-    accum = torch.zeros((H, W, 4), device="cuda", dtype=torch.float32)
-    r.bind_tensor(accum)
-    r.set_frames_in_flight(args.frames_in_flight)
-
-    K, Wm = args.steps, args.warmup
-    sched = progressive_schedule(0, Wm + K, world, rank, spp)
-    if args.scaling == "strong" and world > 1:
-        # warm-up as above; then this rank's contiguous share of the K timed steps
-        from path_tracer_amd.distributed import partition
-        first = Wm * world * spp
-        begin, count = partition(K, world, rank)
-        sched = sched[:Wm] + [(first + (begin + g) * spp, spp) for g in range(count)]
 
     def barrier():
         if world > 1:
@@ -126,111 +113,175 @@ def main() -> int:
             dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    # set-up, not a step: one launch per chain loads the kernels and allocates the chains' buffers
-    # (hipMalloc on first use), then the buffer is cleared again
-    for k in range(args.frames_in_flight):
-        r.render(k, spp, params)
-    r.flush()
-    torch.cuda.synchronize()
-    accum.zero_()
-    torch.cuda.synchronize()
-    stage("set-up done")
-    for s0, n in sched[:Wm]:
-        r.render(s0, n, params)
-    r.flush()
-    stage("warm-up enqueued")
-    if world > 1:  # warm the collective too
-        reduce_accum(accum.clone())
-        stage("collective warmed")
-    barrier()
-    stage("timed region starts")
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for s0, n in sched[Wm:]:
-        r.render(s0, n, params)
-    r.flush()  # frames in flight: the launch stream waits for every chain and folds their sums (asynchronous)
-    ev1.record()
-    if world > 1:
-        reduce_accum(accum, dst=0)
-    if rank == 0:
-        r.resolve(abi.RESOLVE_RGBA8_CUDA)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    stage("timed region done")
-    if rank == 0:
-        # every pixel now holds the samples of every rank (warm-up frames included), each once
-        want_w = float((world * Wm + (K if args.scaling == "strong" else world * K)) * spp)
-        w_min, w_max = float(accum[..., 3].min()), float(accum[..., 3].max())
-        if w_min != want_w or w_max != want_w:
-            print(f"bench.py: accumulation buffer holds {w_min}..{w_max} samples per pixel, expected {want_w}", file=sys.stderr)
-            return 3
-    # HIP events on the launch stream around the K launches (the chains fork from and join this stream):
-    # the time per launch the chip needed, with `frames_in_flight` launches overlapping
-    my_steps = len(sched) - Wm
-    kernel_ms = ev0.elapsed_time(ev1) / max(my_steps, 1)
-    # the same launches strictly one after another, for comparison with rocprofv3's per-dispatch durations
-    serial_ms = kernel_ms
-    if args.frames_in_flight > 1:
-        r.set_frames_in_flight(1)
-        n_serial = min(my_steps, 128)
-        torch.cuda.synchronize()
-        ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev2.record()
-        for s0, n in sched[Wm:Wm + n_serial]:
-            r.render(s0, n, params)
-        ev3.record()
-        torch.cuda.synchronize()
-        serial_ms = ev2.elapsed_time(ev3) / max(n_serial, 1)
-    if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+    flags = abi.FLAG_NEE_MIS if args.mis else 0
+    r = Renderer(local_rank)
+    r.use_torch_stream()
 
-    samples_per_step = W * H * spp
-    total_steps = K if args.scaling == "strong" else world * K
-    value = total_steps * samples_per_step / elapsed / 1e6
+    def run_leg(workload, K, Wm, scaling, serial_probe):
+        """One workload: set-up, Wm untimed warm-up steps, then K timed steps bracketed by barrier + synchronize on
+        both sides (the reduce and rank 0's resolve inside), MAX over ranks.  Returns the numbers of the leg."""
+        scene_name, W, H, spp, max_depth = WORKLOADS[workload]
+        scene, cam = scenes.builtin(scene_name, W, H)
+        params = abi.render_params(max_depth=max_depth, flags=flags, fused_rgba8=1, pixels_per_wave=args.pixels_per_wave)
+        if r._bound is not None:
+            r.unbind()
+        r.set_frames_in_flight(1)
+        r.set_scene(scene)
+        r.set_camera(cam)
+        accum = torch.zeros((H, W, 4), device="cuda", dtype=torch.float32)
+        r.bind_tensor(accum)
+        r.set_frames_in_flight(args.frames_in_flight)
+        flight = r.frames_in_flight()
+
+        if scaling == "strong":   # warm-up on every rank; then this rank's contiguous share of the K timed steps
+            sched = progressive_schedule(0, Wm, world, rank, spp) + strong_schedule(Wm * world * spp, K, world, rank, spp)
+        else:
+            sched = progressive_schedule(0, Wm + K, world, rank, spp)
+
+        # set-up, not a step: one launch per chain loads the kernels and allocates the chains' buffers
+        # (hipMalloc on first use), then the buffer is cleared again
+        for k in range(flight):
+            r.render(k, spp, params)
+        r.flush()
+        torch.cuda.synchronize()
+        accum.zero_()
+        torch.cuda.synchronize()
+        stage(f"{workload}: set-up done")
+        for s0, n in sched[:Wm]:
+            r.render(s0, n, params)
+        r.flush()
+        if world > 1:  # warm the collective too
+            reduce_accum(accum.clone())
+        barrier()
+        stage(f"{workload}: timed region starts")
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for s0, n in sched[Wm:]:
+            r.render(s0, n, params)
+        r.flush()  # frames in flight: the launch stream waits for the last fold pass (asynchronous)
+        ev1.record()
+        t_render = t_reduce = None
+        if world > 1:
+            torch.cuda.synchronize()
+            t_render = time.perf_counter()
+            reduce_accum(accum, dst=0)
+            torch.cuda.synchronize()
+            t_reduce = time.perf_counter()
+        if rank == 0:
+            r.resolve(abi.RESOLVE_RGBA8_CUDA)
+        barrier()
+        t_end = time.perf_counter()
+        elapsed = t_end - t0
+        stage(f"{workload}: timed region done")
+        total_steps = K if scaling == "strong" else world * K
+        if rank == 0:
+            # every pixel now holds the samples of every rank (warm-up steps included), each once
+            want_w = float((world * Wm + total_steps) * spp)
+            w_min, w_max = float(accum[..., 3].min()), float(accum[..., 3].max())
+            if w_min != want_w or w_max != want_w:
+                raise RuntimeError(f"{workload}: accumulation buffer holds {w_min}..{w_max} samples per pixel, expected {want_w}")
+        my_steps = len(sched) - Wm
+        # HIP events on the launch stream around this rank's launches (the chains fork from and join this stream): the
+        # time per launch the chip needed with `flight` launches overlapping = first start to last end / launches
+        kernel_ms = ev0.elapsed_time(ev1) / max(my_steps, 1)
+        serial_ms = None
+        if serial_probe and flight > 1 and my_steps > 0:
+            # the same launches strictly one after another, for comparison with rocprofv3's per-dispatch durations
+            r.set_frames_in_flight(1)
+            n_serial = min(my_steps, 128)
+            torch.cuda.synchronize()
+            ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev2.record()
+            for s0, n in sched[Wm:Wm + n_serial]:
+                r.render(s0, n, params)
+            ev3.record()
+            torch.cuda.synchronize()
+            serial_ms = ev2.elapsed_time(ev3) / n_serial
+        render_s = (t_render - t0) if t_render else elapsed
+        reduce_s = (t_reduce - t_render) if t_reduce else 0.0
+        if world > 1:
+            t = torch.tensor([elapsed, kernel_ms, render_s, reduce_s], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, kernel_ms, render_s, reduce_s = (float(v) for v in t)
+        out = {"workload": workload, "scene": scene_name, "width": W, "height": H, "spp_per_step": spp, "max_depth": max_depth,
+               "steps": K, "warmup": Wm, "scaling": scaling if world > 1 else "weak", "frames_in_flight": flight,
+               "elapsed_s": elapsed, "total_steps": total_steps, "samples_per_step": W * H * spp,
+               "value": total_steps * W * H * spp / elapsed / 1e6, "kernel_ms": kernel_ms, "serial_ms": serial_ms,
+               "render_ms": render_s * 1e3, "reduce_ms": reduce_s * 1e3, "my_steps": my_steps}
+        if rank == 0:
+            # ---- algorithmic FLOPs per launch from the instrumented kernel (same samples as timed steps) --
+            r.unbind()
+            r.set_frames_in_flight(1)
+            r.reset()
+            r.reset_counters()
+            cp = abi.render_params(max_depth=max_depth, flags=flags | abi.FLAG_COUNTERS, pixels_per_wave=args.pixels_per_wave)
+            n_cnt = max(1, min(my_steps, 8 if W * H * spp < (1 << 24) else 1))
+            for s0, n in sched[Wm:Wm + n_cnt]:
+                r.render(s0, n, cp)
+            cnt = r.counters().as_dict()
+            out["flops_per_launch"] = algorithmic_flops(cnt, scene.num_spheres, scene.num_planes, scene.num_triangles, W * H * n_cnt) / n_cnt
+            out["rays_per_sample"] = cnt["rays"] / max(cnt["samples"], 1)
+        out["_scene"], out["_cam"], out["_params"] = scene, cam, params
+        return out
+
+    try:
+        head = run_leg(args.workload, args.steps, args.warmup, args.scaling, serial_probe=True)
+        leg4k = None
+        if not args.no_4k_leg and not args.mis:
+            leg4k = run_leg(LEG_4K[0], LEG_4K[1], LEG_4K[2], "strong", serial_probe=False)
+    except RuntimeError as e:
+        print(f"bench.py: {e}", file=sys.stderr)
+        return 3
+
+    def roofline(leg, with_traffic):
+        achieved = leg["flops_per_launch"] / (leg["kernel_ms"] * 1e-3) / 1e12
+        d = {"bound": "valu", "kernel": "pt_path_kernel", "achieved": round(achieved, 4), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": None, "flops_per_launch": leg["flops_per_launch"],
+             "flops_per_sample": round(leg["flops_per_launch"] / leg["samples_per_step"], 1),
+             "kernel_ms": round(leg["kernel_ms"], 5), "launch_overlap": leg["frames_in_flight"]}
+        if with_traffic:
+            pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+            if os.path.exists(pmc):
+                try:
+                    d["traffic"] = json.load(open(pmc)).get(leg["workload"], {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    pass
+        if leg["serial_ms"]:
+            d["kernel_ms_serial"] = round(leg["serial_ms"], 5)
+            d["frac_serial"] = round(leg["flops_per_launch"] / (leg["serial_ms"] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 5)
+        return d
 
     result = None
     if rank == 0:
-        # ---- algorithmic FLOPs per launch from the instrumented kernel (same samples as timed steps) --
-        r.unbind()
-        r.reset()
-        r.reset_counters()
-        cp = abi.render_params(max_depth=max_depth, flags=flags | abi.FLAG_COUNTERS, pixels_per_wave=args.pixels_per_wave)
-        n_cnt = max(1, min(my_steps, 8))
-        for s0, n in sched[Wm:Wm + n_cnt]:
-            r.render(s0, n, cp)
-        cnt = r.counters().as_dict()
-        flops_per_launch = algorithmic_flops(cnt, scene.num_spheres, scene.num_planes, scene.num_triangles, W * H * n_cnt) / n_cnt
-        rays_per_sample = cnt["rays"] / max(cnt["samples"], 1)
-        achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        K = args.steps
         result = {
-            "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
-            "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True,
-            "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "scene": scene_name, "width": W, "height": H, "spp_per_step": spp,
-                       "max_depth": max_depth, "integrator": "path+nee_mis" if args.mis else "path",
-                       "accumulate": "sum+fused_rgba8", "frames_in_flight": args.frames_in_flight, "parallelism": f"sample_split{world}" if world > 1 else "single",
+            "metric": "Msamples/s", "value": round(head["value"], 3), "unit": "Msamples/s", "n_gpus": world,
+            "steps": K, "warmup": args.warmup, "ms_per_step": round(head["elapsed_s"] / K * 1e3, 5), "higher_is_better": True,
+            "scaling": head["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": head["workload"], "scene": head["scene"], "width": head["width"], "height": head["height"],
+                       "spp_per_step": head["spp_per_step"], "max_depth": head["max_depth"], "integrator": "path+nee_mis" if args.mis else "path",
+                       "accumulate": "sum+display_rgba8_per_frame", "frames_in_flight": head["frames_in_flight"],
+                       "parallelism": f"sample_split{world}" if world > 1 else "single",
                        "reduce": ("gloo_rehearsal_on_one_gpu" if rehearsal else "rccl_reduce_sum_once") if world > 1 else None},
-            "mrays_per_s": round(value * rays_per_sample, 1), "rays_per_sample": round(rays_per_sample, 4),
-            "roofline": {"bound": "valu", "kernel": "pt_path_kernel", "achieved": round(achieved, 4),
-                         "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5),
-                         "traffic": traffic, "flops_per_launch": flops_per_launch,
-                         "flops_per_sample": round(flops_per_launch / samples_per_step, 1),
-                         "kernel_ms": round(kernel_ms, 5), "launch_overlap": args.frames_in_flight,
-                         "kernel_ms_serial": round(serial_ms, 5),
-                         "frac_serial": round(flops_per_launch / (serial_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 5)},
+            "mrays_per_s": round(head["value"] * head["rays_per_sample"], 1), "rays_per_sample": round(head["rays_per_sample"], 4),
+            "roofline": roofline(head, True),
         }
+        if world > 1:  # the collective and the rest of the timed region, apart (max over ranks)
+            result["render_ms"] = round(head["render_ms"], 4)
+            result["reduce_ms"] = round(head["reduce_ms"], 4)
+            result["resolve_and_barrier_ms"] = round(head["elapsed_s"] * 1e3 - head["render_ms"] - head["reduce_ms"], 4)
+        if leg4k:
+            l = leg4k
+            result["legs"] = {"cornell_4k_1024spp_strong_split": {
+                "baseline_config": 3, "metric": "Msamples/s", "value": round(l["value"], 3), "mrays_per_s": round(l["value"] * l["rays_per_sample"], 1),
+                "n_gpus": world, "scaling": "strong", "width": l["width"], "height": l["height"], "spp_total": l["steps"] * l["spp_per_step"],
+                "spp_per_step": l["spp_per_step"], "steps": l["steps"], "steps_per_rank_max": -(-l["steps"] // world), "warmup": l["warmup"],
+                "wall_ms": round(l["elapsed_s"] * 1e3, 3), "render_ms": round(l["render_ms"], 3), "reduce_ms": round(l["reduce_ms"], 3),
+                "reduce_bytes": l["width"] * l["height"] * 16 if world > 1 else 0, "frames_in_flight": l["frames_in_flight"],
+                "roofline": roofline(l, False)}}
         if world == 1 and args.cpu_seconds > 0:
-            result["cpu_baseline"] = cpu_baseline(scene, cam, params, spp, args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(head["_scene"], head["_cam"], head["_params"], head["spp_per_step"], args.cpu_seconds)
     if world > 1:
         dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
@@ -265,7 +316,8 @@ def cpu_baseline(scene, cam, params, spp, budget_s):
     n = cam.width * cam.height * spp * frames
     return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"{frames} frames of {cam.width}x{cam.height} at {spp} spp ({n} samples, {dt:.1f} s), "
-                      "oracle/libpt_oracle.so float build, gcc -O2 -fopenmp"}
+                      "oracle/libpt_oracle.so float build (gcc -O2 -ffp-contract=off -fopenmp: the checker's own build, "
+                      "made in the build container; -march=native cannot travel to the GPU box)"}
 
 
 if __name__ == "__main__":

@@ -16,6 +16,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <cstdlib>
 #include <string>
@@ -52,7 +53,16 @@ int pt_fail(int code, const char* fmt, ...) {
 }
 void pt_clear_error() { g_err.clear(); }
 
+// PT_AMD_HOSTPROF=1: host time spent in the HIP calls of the overlapped launch path, printed at pt_destroy
+struct HostProf {
+    bool on = false;
+    double t[6] = {}; uint64_t n[6] = {};
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+};
+#define PROF(ctx, slot, expr) do { if ((ctx)->prof.on) { const double t0_ = HostProf::now(); HIP_TRY(expr); (ctx)->prof.t[slot] += HostProf::now() - t0_; (ctx)->prof.n[slot]++; } else HIP_TRY(expr); } while (0)
+
 struct PtContext {
+    HostProf prof;
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -90,6 +100,8 @@ struct PtContext {
     hipEvent_t fold_done[PT_MAX_CHAINS] = {};  // per chain: the fold pass behind its last launch (and, through the chain of
                                                // waits, every earlier fold pass of the burst) is done
     bool display_current = false;           // the display buffer holds the mean of everything folded so far
+    uint32_t folds_queued = 0;              // fold passes of the open burst enqueued so far (launches 0 .. folds_queued-1)
+    bool fold_rgba[PT_MAX_CHAINS] = {};     // per chain: the launch whose fold pass is not enqueued yet asked for a display
     uint32_t burst = 0;                // launches since the chains were last joined
     bool burst_displayed = false;      // some launch of the burst asked for a display
     uint32_t compute_units = 256;
@@ -117,6 +129,7 @@ int use(PtContext* ctx) {
 }
 
 int join_chains(PtContext* ctx);
+int queue_next_fold(PtContext* ctx);
 
 int alloc_frame(PtContext* ctx, uint32_t w, uint32_t h) {
     if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) return fail(PT_ERR_INVALID, "bad frame size %ux%u", w, h);
@@ -151,14 +164,36 @@ int alloc_frame(PtContext* ctx, uint32_t w, uint32_t h) {
 
 constexpr size_t WORK_SET_WORDS = 256;  // 8 shards x 32 words (128 B apart)
 
+// Frames in flight: enqueues the fold pass of the oldest launch of the burst that has none yet.  It runs behind its
+// launch on the chain's own stream (no stream of its own: HIP's default is 4 hardware queues per process, and streams
+// that share one serialise) and after the fold pass of the launch before it, whichever chain that ran on: the
+// accumulation buffer receives the launches in launch order.  That cross-stream wait is the expensive call of the
+// frame loop (hipStreamWaitEvent on an event still pending on another stream: 26 us of host time against 3 us for a
+// kernel launch), so a fold pass is enqueued as late as it may be: when its chain is about to launch again, or when
+// the burst is joined.  The first launches of a burst therefore leave the host 3 us apart and fill the chip at once.
+int queue_next_fold(PtContext* ctx) {
+    const uint32_t k = ctx->folds_queued, chain = k % ctx->flight;
+    hipStream_t stream = ctx->chain_stream[chain];
+    if (k > 0) PROF(ctx, 2, hipStreamWaitEvent(stream, ctx->fold_done[(k - 1u) % ctx->flight], 0));
+    PROF(ctx, 3, pt_launch_fold(ctx->accum, ctx->chain_acc[chain], ctx->fold_rgba[chain] ? (uint32_t*)ctx->display : nullptr,
+                                ctx->width * ctx->height, stream));
+    PROF(ctx, 4, hipEventRecord(ctx->fold_done[chain], stream));
+    ctx->display_current = ctx->fold_rgba[chain];
+    ctx->folds_queued++;
+    return PT_OK;
+}
+
 // Frames in flight: makes the context's stream wait for the last fold pass (each waits for the one before it, so
 // that one is behind all others).  A no-op when no burst is open.  Nothing is left to add up: every
 // launch's sums are already in the accumulation buffer, in launch order.
 int join_chains(PtContext* ctx) {
     if (ctx->burst == 0) return PT_OK;
+    while (ctx->folds_queued < ctx->burst)
+        if (int rc = queue_next_fold(ctx)) return rc;
     const uint32_t last = (ctx->burst - 1u) % ctx->flight;
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->fold_done[last], 0));
     ctx->burst = 0;
+    ctx->folds_queued = 0;
     if (ctx->burst_displayed && !ctx->display_current) {
         // some launch of the burst asked for a display and a later one did not: redo it from the sums
         HIP_TRY(pt_launch_resolve(ctx->accum, ctx->display, ctx->width * ctx->height, PT_ACC_SUM, PT_RESOLVE_RGBA8_CUDA, ctx->stream));
@@ -309,7 +344,9 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
         chain = ctx->burst % ctx->flight;
         stream = ctx->chain_stream[chain];
         // (a chain's launches and fold passes alternate on its stream: its buffer is folded before it is written again)
-        if (ctx->burst < ctx->flight) HIP_TRY(hipStreamWaitEvent(stream, ctx->fork_event, 0));  // first launch of this chain in the burst
+        if (ctx->burst < ctx->flight) PROF(ctx, 0, hipStreamWaitEvent(stream, ctx->fork_event, 0));  // first launch of this chain in the burst
+        while (ctx->burst >= ctx->flight && ctx->folds_queued + ctx->flight <= ctx->burst)
+            if (int rc = queue_next_fold(ctx)) return rc;
     } else {
         if (int rc = join_chains(ctx)) return rc;
     }
@@ -425,17 +462,10 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
         HIP_TRY(hipMemsetAsync(ctx->trace, 0, waves * 128, stream));
         a.trace = ctx->trace;
     } else a.trace = nullptr;
-    HIP_TRY(pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, few, blocks, stream));
+    PROF(ctx, 1, pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, few, blocks, stream));
     if (pipelined) {
-        // The fold pass runs behind the launch on the chain's own stream (no stream of its own: HIP's default is 4
-        // hardware queues per process, and streams that share one serialise) and after the fold pass of the launch
-        // before it, whichever chain that ran on: the accumulation buffer receives the launches in launch order.
-        if (ctx->burst > 0) HIP_TRY(hipStreamWaitEvent(stream, ctx->fold_done[(ctx->burst - 1u) % ctx->flight], 0));
-        HIP_TRY(pt_launch_fold(ctx->accum, ctx->chain_acc[chain], prm->fused_rgba8 ? (uint32_t*)ctx->display : nullptr,
-                               ctx->width * ctx->height, stream));
-        HIP_TRY(hipEventRecord(ctx->fold_done[chain], stream));
+        ctx->fold_rgba[chain] = prm->fused_rgba8 != 0;   // its fold pass is enqueued later (queue_next_fold)
         if (prm->fused_rgba8) ctx->burst_displayed = true;
-        ctx->display_current = prm->fused_rgba8 != 0;
         ctx->burst++;
     }
     if (trace_file) {
@@ -473,6 +503,7 @@ int pt_create(int device_id, PtContext** out) {
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
             ctx->compute_units = (uint32_t)prop.multiProcessorCount;
     }
+    if (const char* e = getenv("PT_AMD_HOSTPROF")) ctx->prof.on = atoi(e) != 0;
     if (const char* e = getenv("PT_AMD_FEW_MAX")) ctx->knob_few_max = atoi(e);
     if (const char* e = getenv("PT_AMD_MAX_BLOCKS")) ctx->knob_max_blocks = atoi(e);
     if (const char* e = getenv("PT_AMD_TRACE")) ctx->knob_trace = e;
@@ -506,6 +537,11 @@ int pt_create(int device_id, PtContext** out) {
 int pt_destroy(PtContext* ctx) {
     pt_clear_error();
     if (!ctx) return PT_OK;
+    if (ctx->prof.on) {
+        static const char* const names[5] = {"wait fork event", "launch path kernel", "wait previous fold", "launch fold pass", "record fold event"};
+        for (int k = 0; k < 5; ++k)
+            if (ctx->prof.n[k]) fprintf(stderr, "[pt hostprof] %-20s %8llu calls  %7.2f us each\n", names[k], (unsigned long long)ctx->prof.n[k], ctx->prof.t[k] / (double)ctx->prof.n[k]);
+    }
     (void)hipSetDevice(ctx->device);
     for (uint32_t c = 0; c < PT_MAX_CHAINS; ++c) {
         if (c > 0 && ctx->chain_stream[c]) { (void)hipStreamSynchronize(ctx->chain_stream[c]); (void)hipStreamDestroy(ctx->chain_stream[c]); }

@@ -35,6 +35,14 @@ def progressive_schedule(first_sample: int, steps: int, world_size: int, rank: i
     return out
 
 
+def strong_schedule(first_sample: int, steps: int, world_size: int, rank: int, spp_per_step: int = 1) -> List[Tuple[int, int]]:
+    """Per-step (sample_begin, sample_count) of THIS rank when `steps` steps of `spp_per_step` samples, starting at
+    sample `first_sample`, are divided among the ranks (strong scaling, BASELINE config 3): rank r gets a contiguous
+    run of steps, shares differing by at most one step.  Over all ranks every sample appears exactly once."""
+    begin, count = partition(steps, world_size, rank)
+    return [(first_sample + (begin + g) * spp_per_step, spp_per_step) for g in range(count)]
+
+
 def render_split(render_fn: Callable[[int, int], None], total_samples: int, world_size: int, rank: int,
                  chunk: int = 64, first_sample: int = 0) -> int:
     """Strong scaling: trace this rank's share of `total_samples` in launches of at most `chunk`."""

@@ -34,6 +34,21 @@ def test_progressive_schedule_is_disjoint_and_dense():
     assert sorted(seen) == list(range(10, 10 + world * steps * spp))
 
 
+def test_strong_schedule_divides_the_steps():
+    """bench.py's config-3 leg: 64 steps of 16 spp divided among the ranks, uneven shares included."""
+    for world in (1, 2, 3, 4, 8, 5):
+        for steps, spp, first in ((64, 16, 96), (7, 3, 0), (2, 1, 5)):
+            seen, shares = [], []
+            for r in range(world):
+                sched = distributed.strong_schedule(first, steps, world, r, spp)
+                shares.append(len(sched))
+                for s0, n in sched:
+                    assert n == spp
+                    seen += list(range(s0, s0 + n))
+            assert sorted(seen) == list(range(first, first + steps * spp)) and len(seen) == len(set(seen))
+            assert max(shares) - min(shares) <= 1 and sum(shares) == steps
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -56,9 +71,12 @@ def _worker(rank, world, port, total, out_path):
     def render(s0, n):
         oracle.render_path(sc, cam, s0, n, p, precision=32, accum=acc)
 
-    # strong scaling: this rank's share of `total` samples, then progressive frames on top
+    # strong scaling: this rank's share of `total` samples, then progressive frames on top, then bench.py's
+    # config-3 schedule (5 steps of 2 samples divided among the ranks: uneven for 2, 3 and 8 ranks)
     distributed.render_split(render, total, world, rank, chunk=3)
     for s0, n in distributed.progressive_schedule(total, 2, world, rank, 1):
+        render(s0, n)
+    for s0, n in distributed.strong_schedule(total + 2 * world, 5, world, rank, 2):
         render(s0, n)
     t = torch.from_numpy(acc)
     distributed.reduce_accum(t, dst=0)
@@ -68,15 +86,18 @@ def _worker(rank, world, port, total, out_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_sample_split_equals_single_rank(tmp_path, oracle):
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sample_split_over_ranks_equals_single_rank(tmp_path, oracle, world):
+    """world_size 2, 3 and 8 over gloo (uneven shares for every schedule): the reduced buffer holds every sample once."""
     import torch.multiprocessing as mp
-    total, world = 10, 2
+    total = 10
     out = str(tmp_path / "reduced.npy")
     mp.spawn(_worker, args=(world, _free_port(), total, out), nprocs=world, join=True)
     got = np.load(out)
     sc, cam = scenes.cuda_default(32, 18)
-    want = oracle.render_path(sc, cam, 0, total + 2 * world, abi.render_params(), precision=32)
-    assert np.all(got[..., 3] == total + 2 * world)          # counts combined by the same reduce
+    n = total + 2 * world + 5 * 2
+    want = oracle.render_path(sc, cam, 0, n, abi.render_params(), precision=32)
+    assert np.all(got[..., 3] == n)                           # counts combined by the same reduce
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)  # equal up to FP32 summation order
 
 

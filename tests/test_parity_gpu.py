@@ -1236,5 +1236,9 @@ def test_bench_line_contract():
     r = d["roofline"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1 and r["unit"] == "TFLOP/s"
     assert abs(d["value"] - 1280 * 720 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    # the 4K leg (BASELINE config 3 at N = 1: 64 steps of 16 spp = 1024 spp)
+    l = d["legs"]["cornell_4k_1024spp_strong_split"]
+    assert l["spp_total"] == 1024 and l["width"] == 3840 and l["value"] > 0 and 0 < l["roofline"]["frac"] < 1
+    assert abs(l["value"] - 3840 * 2160 * 1024 / (l["wall_ms"] * 1e-3) / 1e6) < 0.01 * l["value"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == d["unit"]

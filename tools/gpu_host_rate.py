@@ -19,3 +19,4 @@ for flight in (1, 8):
     r.sync()
     t2 = time.perf_counter()
     print(f"flight {flight}: enqueue {1e6 * (t1 - t0) / K:.1f} us/frame, total {1e6 * (t2 - t0) / K:.1f} us/frame", flush=True)
+r.close()
