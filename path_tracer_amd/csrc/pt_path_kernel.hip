@@ -27,6 +27,17 @@
 
 #include <mutex>
 
+// build switches of the A/B variants (make variant NAME=x VFLAGS=-DPT_...=0); the defaults are the measured winners
+#ifndef PT_UPD
+#define PT_UPD 1
+#endif
+#ifndef PT_REGEN
+#define PT_REGEN 2
+#endif
+#ifndef PT_ONB
+#define PT_ONB 1
+#endif
+
 // ---- scratch of the entry point that allocates nothing (pt_render_noalloc, include/pt.h) ------------------
 // The path kernel's only memory beyond its inputs and outputs is its ticket counters.  pt_render takes them from a
 // hipMalloc made at pt_create; callers that cannot allocate (HIP graph capture, serving loops) get them from this
@@ -104,11 +115,26 @@ __device__ __forceinline__ uint32_t pt_draw(uint32_t key, uint32_t slot, uint32_
 // (0,1], the range of curand_uniform which the reference's samplers are written for.
 __device__ __forceinline__ float uni(uint32_t bits) { return (float)((bits >> 8) + 1u) * (1.0f / 16777216.0f); }
 
-// ONB of Lambertian_t::scatter, Material.cuh:50-53
+// ONB of Lambertian_t::scatter, Material.cuh:50-53:  a = |w.x| > 0.9 ? (0,1,0) : (1,0,0);  v = normalize(w x a);
+// u = v x w.  With a an axis the first cross product is a permutation, (0, w.z, -w.y) or (-w.z, 0, w.x), its
+// squared length two terms and one component of v zero, so the second cross product is two terms short: the
+// same numbers in 17 instructions instead of 28 (the general formulas multiplied the zeros out).
 __device__ __forceinline__ void onb(V3 w, V3& u, V3& v) {
+#if PT_ONB == 1
+    const bool ay = fabsf(w.x) > 0.9f;
+    const float q = ay ? w.x : w.y;                    // the other non-zero component of w x a, up to sign
+    const float l2 = fmaf(q, q, w.z * w.z);
+    const float il = l2 > 0.0f ? rsq(l2) : 1.0f;       // normalized() leaves a zero vector as it is
+    const float vz = (ay ? q : -q) * il, vo = w.z * il;
+    v = ay ? v3(-vo, 0.0f, vz) : v3(0.0f, vo, vz);
+    // u = v x w with v.x == 0 or v.y == 0
+    u = ay ? v3(-(v.z * w.y), v.z * w.x - v.x * w.z, v.x * w.y)
+           : v3(v.y * w.z - v.z * w.y, v.z * w.x, -(v.y * w.x));
+#else
     V3 a = (fabsf(w.x) > 0.9f) ? v3(0, 1, 0) : v3(1, 0, 0);
     v = normalized(cross(w, a));
     u = cross(v, w);
+#endif
 }
 
 // Scene operands of the intersection loops are read through the CONSTANT address space with a
@@ -140,12 +166,6 @@ constexpr uint32_t EPS_BITS = 0x38D1B717u;                 // bits of 1e-4f (RAY
 constexpr uint32_t TB_INIT = 0x461C4001u - EPS_BITS;        // bits(T_BEST_INIT) - EPS_BITS
 __device__ __forceinline__ uint32_t t_key(float t) { return __float_as_uint(t) - EPS_BITS; }
 __device__ __forceinline__ float t_of_key(uint32_t k) { return __uint_as_float(k + EPS_BITS); }
-#ifndef PT_UPD
-#define PT_UPD 1
-#endif
-#ifndef PT_REGEN
-#define PT_REGEN 2
-#endif
 __device__ __forceinline__ void closer(bool also, float t, int id, uint32_t& tb, int& ib) {
     const uint32_t k = t_key(t);
 #if PT_UPD == 1
@@ -402,7 +422,11 @@ __device__ __forceinline__ const PT_CONST KArgs* cold() {
 #ifndef PT_BLOCK
 #define PT_BLOCK 64
 #endif
+#ifdef PT_NUM_SGPR
+#define PT_OCC __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU), amdgpu_num_sgpr(PT_NUM_SGPR)))
+#else
 #define PT_OCC __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU)))
+#endif
 
 // FEW: the build with the lane-parallel closest hit.  Its mere presence costs the common loop 11 VGPRs and
 // 2-3 % (Cornell box, several samples per launch, overlapped launches), and it pays where waves drain alone
@@ -607,9 +631,11 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
                             const float rough = g2.x;  // clamped to <= 1 for Metal at upload (Material.cuh:94)
                             V3 pv;
                             if (mtype == MAT_METAL) {
-                                // Metal_t::scatter, Material.cuh:97-121 (roughness 0: refl + pv * 0 == refl)
+                                // Metal_t::scatter, Material.cuh:97-121: the perturbation, and its third draw, only for a
+                                // rough metal (:107; the palette's two metals are mirrors: refl + pv * 0 == refl)
                                 if (COUNT) c_b1++;
-                                pv = v3(u0 * 2.0f - 1.0f, u1 * 2.0f - 1.0f, uni(pt_draw(key, slot, 2)) * 2.0f - 1.0f);
+                                pv = v3(0, 0, 0);
+                                if (rough > 0.0f) pv = v3(u0 * 2.0f - 1.0f, u1 * 2.0f - 1.0f, uni(pt_draw(key, slot, 2)) * 2.0f - 1.0f);
                             } else {
                                 // Glossy_t::scatter, Material.cuh:191-213; Random_t::randomUnitVector, Random.cuh:36-45
                                 if (COUNT) c_b3++;
