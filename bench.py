@@ -3,7 +3,10 @@
 Headline workload (BASELINE.json configs[1], the configuration the metric is quoted on that fits one
 GPU): the Cornell box of cuda_pathtracer/src/main.cu at 1280x720, progressive rendering at
 1 sample per pixel per frame with the display (RGBA8) made for every frame.
-A "step" is one frame: one launch of the path kernel over all 921 600 pixels.
+A "step" is one frame: one pt_render call over all 921 600 pixels, the call the reference's frame loop makes
+(launchRenderKernel, main.cu:287).  With frames in flight (the default here) the library collects consecutive frames
+into one launch of the path kernel (up to 32; include/pt.h) and folds them into the accumulation buffer one by one,
+making every frame's RGBA8 display on the way: same sums and same pictures as one launch per frame, bit for bit.
   N = 1 : K frames on one GPU.
   N > 1 : sample-split, weak scaling — every rank renders K frames of 1 spp for its own
           disjoint sample indices, then the float4 accumulation buffers are summed once with an
@@ -59,8 +62,9 @@ def main() -> int:
     ap.add_argument("--workload", default="cornell_720p_progressive_1spp", choices=sorted(WORKLOADS))
     ap.add_argument("--mis", action="store_true", help="next-event estimation + MIS (north_star variant)")
     ap.add_argument("--pixels-per-wave", type=int, default=0)
-    ap.add_argument("--frames-in-flight", type=int, default=8, choices=tuple(range(1, 9)),
-                    help="consecutive launches overlapped on internal streams (include/pt.h); 1 = strictly serial launches")
+    ap.add_argument("--frames-in-flight", type=int, default=3, choices=tuple(range(1, 9)),
+                    help="launches overlapped on internal streams, each holding up to 32 consecutive frames (include/pt.h); "
+                         "1 = one serial launch per frame.  3 is what HIP's default of 4 hardware queues per process allows")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
                     help="headline leg only. weak: every rank renders K steps (default, the driver's contract); strong: the K "
@@ -71,11 +75,10 @@ def main() -> int:
                          "numbers mean nothing)")
     args = ap.parse_args()
 
-    # frames in flight need one hardware queue per chain plus a few for the launch stream and torch's own;
-    # HIP's default of 4 per process makes chains share a queue (and serialise) from 4 chains on, and the library
-    # grants only what the variable leaves room for (pt_set_frames_in_flight): 8 chains with 12 or more
-    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
-        os.environ["GPU_MAX_HW_QUEUES"] = "16"
+    # more than 3 chains need more hardware queues than HIP's default of 4 per process (the library grants only what
+    # the variable leaves room for, pt_set_frames_in_flight); the default of 3 runs on the environment as it is
+    if args.frames_in_flight > 3 and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < args.frames_in_flight + 4:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.frames_in_flight + 4)
     import torch
     import torch.distributed as dist
 
@@ -138,10 +141,10 @@ def main() -> int:
         else:
             sched = progressive_schedule(0, Wm + K, world, rank, spp)
 
-        # set-up, not a step: one launch per chain loads the kernels and allocates the chains' buffers
-        # (hipMalloc on first use), then the buffer is cleared again
-        for k in range(flight):
-            r.render(k, spp, params)
+        # set-up, not a step: one launch loads the kernels and allocates the chains' buffers (hipMalloc on first
+        # use), then the buffer is cleared again
+        for k in range(max(flight, 2)):
+            r.render(k * spp, spp, params)
         r.flush()
         torch.cuda.synchronize()
         accum.zero_()
@@ -155,12 +158,14 @@ def main() -> int:
         barrier()
         stage(f"{workload}: timed region starts")
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        launches0 = r.path_launches()
         t0 = time.perf_counter()
         ev0.record()
         for s0, n in sched[Wm:]:
             r.render(s0, n, params)
-        r.flush()  # frames in flight: the launch stream waits for the last fold pass (asynchronous)
+        r.flush()  # frames in flight: launches what is held back; the launch stream waits for the last fold pass (asynchronous)
         ev1.record()
+        launches = max(r.path_launches() - launches0, 1)
         t_render = t_reduce = None
         if world > 1:
             torch.cuda.synchronize()
@@ -182,9 +187,10 @@ def main() -> int:
             if w_min != want_w or w_max != want_w:
                 raise RuntimeError(f"{workload}: accumulation buffer holds {w_min}..{w_max} samples per pixel, expected {want_w}")
         my_steps = len(sched) - Wm
-        # HIP events on the launch stream around this rank's launches (the chains fork from and join this stream): the
-        # time per launch the chip needed with `flight` launches overlapping = first start to last end / launches
-        kernel_ms = ev0.elapsed_time(ev1) / max(my_steps, 1)
+        # HIP events on the launch stream around this rank's frames (the chains fork from and join this stream): first
+        # launch start to last fold pass end, per frame -- the path kernel with its launches overlapping, plus the fold
+        # pass of the last launch and the queue latencies between them
+        frame_ms = ev0.elapsed_time(ev1) / max(my_steps, 1)
         serial_ms = None
         if serial_probe and flight > 1 and my_steps > 0:
             # the same launches strictly one after another, for comparison with rocprofv3's per-dispatch durations
@@ -201,13 +207,13 @@ def main() -> int:
         render_s = (t_render - t0) if t_render else elapsed
         reduce_s = (t_reduce - t_render) if t_reduce else 0.0
         if world > 1:
-            t = torch.tensor([elapsed, kernel_ms, render_s, reduce_s], device="cuda", dtype=torch.float64)
+            t = torch.tensor([elapsed, frame_ms, render_s, reduce_s], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed, kernel_ms, render_s, reduce_s = (float(v) for v in t)
+            elapsed, frame_ms, render_s, reduce_s = (float(v) for v in t)
         out = {"workload": workload, "scene": scene_name, "width": W, "height": H, "spp_per_step": spp, "max_depth": max_depth,
                "steps": K, "warmup": Wm, "scaling": scaling if world > 1 else "weak", "frames_in_flight": flight,
                "elapsed_s": elapsed, "total_steps": total_steps, "samples_per_step": W * H * spp,
-               "value": total_steps * W * H * spp / elapsed / 1e6, "kernel_ms": kernel_ms, "serial_ms": serial_ms,
+               "value": total_steps * W * H * spp / elapsed / 1e6, "frame_ms": frame_ms, "launches": launches, "serial_ms": serial_ms,
                "render_ms": render_s * 1e3, "reduce_ms": reduce_s * 1e3, "my_steps": my_steps}
         if rank == 0:
             # ---- algorithmic FLOPs per launch from the instrumented kernel (same samples as timed steps) --
@@ -220,7 +226,7 @@ def main() -> int:
             for s0, n in sched[Wm:Wm + n_cnt]:
                 r.render(s0, n, cp)
             cnt = r.counters().as_dict()
-            out["flops_per_launch"] = algorithmic_flops(cnt, scene.num_spheres, scene.num_planes, scene.num_triangles, W * H * n_cnt) / n_cnt
+            out["flops_per_frame"] = algorithmic_flops(cnt, scene.num_spheres, scene.num_planes, scene.num_triangles, W * H * n_cnt) / n_cnt
             out["rays_per_sample"] = cnt["rays"] / max(cnt["samples"], 1)
         out["_scene"], out["_cam"], out["_params"] = scene, cam, params
         return out
@@ -235,11 +241,16 @@ def main() -> int:
         return 3
 
     def roofline(leg, with_traffic):
-        achieved = leg["flops_per_launch"] / (leg["kernel_ms"] * 1e-3) / 1e12
+        # per launch of the path kernel: a launch holds my_steps / launches frames (1 when the launches are serial)
+        fpl = leg["my_steps"] / leg["launches"]
+        flops_per_launch = leg["flops_per_frame"] * fpl
+        launch_ms = leg["frame_ms"] * fpl   # first start to last end of this rank's launches / launches
+        achieved = flops_per_launch / (launch_ms * 1e-3) / 1e12
         d = {"bound": "valu", "kernel": "pt_path_kernel", "achieved": round(achieved, 4), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-             "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": None, "flops_per_launch": leg["flops_per_launch"],
-             "flops_per_sample": round(leg["flops_per_launch"] / leg["samples_per_step"], 1),
-             "kernel_ms": round(leg["kernel_ms"], 5), "launch_overlap": leg["frames_in_flight"]}
+             "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": None, "flops_per_launch": flops_per_launch,
+             "flops_per_sample": round(leg["flops_per_frame"] / leg["samples_per_step"], 1),
+             "launches": leg["launches"], "frames_per_launch": round(fpl, 3),
+             "kernel_ms": round(launch_ms, 5), "frame_ms": round(leg["frame_ms"], 5), "launch_overlap": leg["frames_in_flight"]}
         if with_traffic:
             pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
             if os.path.exists(pmc):
@@ -249,7 +260,7 @@ def main() -> int:
                     pass
         if leg["serial_ms"]:
             d["kernel_ms_serial"] = round(leg["serial_ms"], 5)
-            d["frac_serial"] = round(leg["flops_per_launch"] / (leg["serial_ms"] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 5)
+            d["frac_serial"] = round(leg["flops_per_frame"] / (leg["serial_ms"] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 5)
         return d
 
     result = None

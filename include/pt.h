@@ -240,30 +240,47 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count,
 #define PT_NOALLOC_MAX_SAMPLES 4096u
 int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32_t height,
                       uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* params);
-/* Frames in flight (1..8, default 1).  With n > 1, consecutive PT_ACC_SUM path
- * launches go round-robin to n internal streams, so launch k+1 fills the compute
- * units that launch k leaves idle while its last long paths finish (the
- * reference's frame loop, main.cu:284-303, serialises launch and display; there is
- * no counterpart).  Each such launch writes its own sums into a buffer of its
- * chain, and a fold pass behind it adds them to the accumulation buffer (and, with
- * fused_rgba8, makes the display from the new sums).  The fold passes run in launch
- * order, so the buffer receives acc += launch k for k = 0, 1, 2, ... exactly as
- * under serial launches: the image is bit-identical to the n = 1 image, and the
- * display behind launch k is the mean of samples 0..k as in the reference's loop.
- * Every call that reads or replaces the accumulation buffer first waits (on the
- * context's stream, not on the host) for the fold passes still queued
- * (pt_resolve, pt_readback*, pt_upload_accum, pt_reset, pt_sync, pt_counters,
- * pt_bind_accum, pt_set_stream, pt_upload_scene, pt_resize); a caller that reads
- * pt_accum_device_ptr() or a bound buffer itself calls pt_flush() first, which is
- * asynchronous on the context's stream.
+/* Frames in flight (1..8, default 1).  The reference's frame loop (main.cu:284-303)
+ * serialises launch and display, one frame at a time; there is no counterpart.
+ * With n > 1 a PT_ACC_SUM path call is a FRAME that the library may hold back and
+ * overlap with others:
+ *  - Consecutive calls with the same parameters and sample count, each starting at
+ *    the sample where the one before it ended (the reference's loop is exactly
+ *    that), are collected -- up to 32 of them, fewer on frames beyond 4 Mpixel
+ *    (2^27 pixel-frames per launch), one on frames wider or taller than 8192 -- and
+ *    leave as ONE launch of the path kernel when that many have gathered or when
+ *    anything needs their result.  The launch hands out (frame, pixel) pairs from one
+ *    ticket space: one ramp and one tail instead of one per frame, and 32 x as many
+ *    work items per lane as a frame has (2.3 pixels per resident lane at 1280x720).
+ *  - Launches go round-robin to n internal streams, so launch k+1 fills the
+ *    compute units that launch k leaves idle while its last long paths finish.
+ *  - Each launch writes the sums of each of its frames into a plane of a buffer of
+ *    its chain, and a fold pass behind it adds them to the accumulation buffer one
+ *    frame after the other (and, with fused_rgba8, makes every frame's display from
+ *    the sums as they stand after it).  The fold passes run in launch order, so
+ *    the buffer receives acc += frame k for k = 0, 1, 2, ... exactly as under serial
+ *    launches: the image is bit-identical to the n = 1 image, and the display made
+ *    for frame k is the mean of samples 0..k as in the reference's loop.  The newest
+ *    display is in the display buffer (pt_readback); the ones the same fold pass
+ *    made before it are kept until the next fold pass (pt_readback_history).
+ * Every call that reads or replaces the accumulation buffer first launches what
+ * is held back and waits (on the context's stream, not on the host) for the fold
+ * passes still queued (pt_resolve, pt_readback*, pt_upload_accum, pt_reset,
+ * pt_sync, pt_counters, pt_bind_accum, pt_set_stream, pt_upload_scene,
+ * pt_set_camera, pt_resize); a caller that reads pt_accum_device_ptr() or a bound
+ * buffer itself, or that waits on its own stream, calls pt_flush() first, which is
+ * asynchronous on the context's stream.  A caller that flushes after every frame
+ * gets serial launches.
  * n > 3 needs more hardware queues than HIP's default of 4 per process:
  * GPU_MAX_HW_QUEUES >= n + 4 in the environment before HIP initialises (16 for
  * n = 8).  Chains that share a queue serialise (with the default, 4 chains are
  * slower than 3), so the request is GRANTED only up to what the variable, as
  * the library finds it at pt_create, leaves room for: 3 chains when it is unset
  * or <= 7, GPU_MAX_HW_QUEUES - 4 beyond that.  The call still returns PT_OK;
- * pt_frames_in_flight() returns the number in effect.  Memory: one buffer of the
- * frame's size (16 B per pixel) per chain.
+ * pt_frames_in_flight() returns the number in effect.  Memory: per chain one
+ * plane of the frame's size (16 B per pixel) for every frame a launch may hold
+ * (472 MB at 1280x720, at most 2 GiB), plus 4 B per pixel and frame for the
+ * display history (one per context).
  *
  * Large calls.  A pixel belongs to one lane per launch, so one long launch over
  * few pixels per lane (2.3 at 1280x720) ends with most lanes idle.  On frames
@@ -279,6 +296,10 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
  * PT_AMD_CHUNK=0, read at pt_create, keeps every call one launch.) */
 int pt_set_frames_in_flight(PtContext* ctx, uint32_t n);
 uint32_t pt_frames_in_flight(PtContext* ctx);
+/* Launches of the path kernel this context has made so far (frames that are held
+ * back are not launched yet): lets a caller relate frames to launches when it
+ * reads a profile. */
+uint64_t pt_path_launches(PtContext* ctx);
 int pt_flush(PtContext* ctx);
 /* Resolve the accumulation buffer into the context's display buffer
  * (convertToRGBAKernel / the CPU accumulate+gamma loop).  Asynchronous. */
@@ -286,6 +307,15 @@ int pt_resolve(PtContext* ctx, uint32_t mode);
 /* Copy the display buffer of the last pt_resolve / fused render to the host
  * (Window_t::updateScreen's cudaMemcpy, Window.cuh:160).  Synchronises. */
 int pt_readback(PtContext* ctx, void* host_dst, size_t bytes);
+/* Frames in flight: the displays (RGBA8, as pt_readback returns them) that the last
+ * fold pass made BEFORE its newest one, which is in the display buffer.
+ * pt_history_frames() returns how many are held (0 .. 31; 0 after anything else
+ * wrote the display: pt_resolve, a serial launch with fused_rgba8, pt_reset);
+ * frames_back = 1 is the frame before the newest.  Both first launch and fold
+ * what is in flight.  No counterpart in the reference, whose loop shows each
+ * frame before it launches the next (Window_t::updateScreen, Window.cuh:160). */
+uint32_t pt_history_frames(PtContext* ctx);
+int pt_readback_history(PtContext* ctx, uint32_t frames_back, void* host_dst, size_t bytes);
 /* Copy the raw accumulation buffer (width*height float4) to the host. Synchronises. */
 int pt_readback_accum(PtContext* ctx, float* host_dst, size_t bytes);
 /* Upload a raw accumulation buffer (resume from a checkpoint). */

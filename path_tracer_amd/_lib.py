@@ -17,9 +17,9 @@ LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(os.path.dirname(os.path.
 SYMBOLS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_abi_version", "pt_set_stream", "pt_use_own_stream", "pt_upload_scene",
     "pt_set_camera", "pt_resize", "pt_bind_accum", "pt_reset", "pt_render", "pt_resolve", "pt_readback",
-    "pt_readback_accum", "pt_upload_accum", "pt_sync", "pt_accum_device_ptr", "pt_display_device_ptr",
+    "pt_readback_accum", "pt_history_frames", "pt_readback_history", "pt_upload_accum", "pt_sync", "pt_accum_device_ptr", "pt_display_device_ptr",
     "pt_primary_ids", "pt_counters", "pt_reset_counters", "pt_valu_peak", "pt_make_current",
-    "launchRenderKernel", "pt_builtin_scene", "pt_set_frames_in_flight", "pt_frames_in_flight", "pt_flush",
+    "launchRenderKernel", "pt_builtin_scene", "pt_set_frames_in_flight", "pt_frames_in_flight", "pt_path_launches", "pt_flush",
     "pt_fly_camera_step", "pt_reduce", "pt_render_noalloc",
 ]
 
@@ -64,6 +64,11 @@ def lib() -> C.CDLL:
     L.pt_resolve.argtypes = [ctx, u32]
     L.pt_readback.argtypes = [ctx, vp, C.c_size_t]
     L.pt_readback_accum.argtypes = [ctx, vp, C.c_size_t]
+    L.pt_path_launches.argtypes = [ctx]
+    L.pt_path_launches.restype = C.c_uint64
+    L.pt_history_frames.argtypes = [ctx]
+    L.pt_history_frames.restype = C.c_uint32
+    L.pt_readback_history.argtypes = [ctx, C.c_uint32, vp, C.c_size_t]
     L.pt_upload_accum.argtypes = [ctx, vp, C.c_size_t]
     L.pt_sync.argtypes = [ctx]
     L.pt_accum_device_ptr.argtypes = [ctx]

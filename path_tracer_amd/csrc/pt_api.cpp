@@ -102,7 +102,14 @@ struct PtContext {
     bool display_current = false;           // the display buffer holds the mean of everything folded so far
     uint32_t folds_queued = 0;              // fold passes of the open burst enqueued so far (launches 0 .. folds_queued-1)
     bool fold_rgba[PT_MAX_CHAINS] = {};     // per chain: the launch whose fold pass is not enqueued yet asked for a display
+    uint32_t chain_frames[PT_MAX_CHAINS] = {};  // per chain: frames of the launch whose fold pass is not enqueued yet
+    size_t chain_planes = 0;           // planes (frames) each chain buffer holds
+    uint32_t* history = nullptr;       // displays of the frames before the newest of the last fold pass, one plane each
+    uint32_t history_frames = 0;       // planes of `history` that hold a picture (frame history_frames-1 is the newest but one)
+    // Frames collected for the next overlapped launch (pt_render calls that were accepted but not launched yet)
+    struct Pending { uint32_t begin = 0, per_frame = 0, frames = 0; PtRenderParams prm{}; } pending;
     uint32_t burst = 0;                // launches since the chains were last joined
+    uint64_t path_launches = 0;        // launches of the path kernel since pt_create (pt_path_launches)
     bool burst_displayed = false;      // some launch of the burst asked for a display
     uint32_t compute_units = 256;
     uint32_t burst_chains = 3;         // most chains worth running at once: 3 on HIP's default 4 hardware queues, else
@@ -113,7 +120,7 @@ struct PtContext {
     uint32_t resident_blocks[8] = {};  // per kernel build (nee, count, few)
     // tuning / tracing knobs for tools/gpu_ab.py and tools/gpu_trace.py, read once at pt_create
     // (PT_AMD_FEW_MAX, PT_AMD_MAX_BLOCKS, PT_AMD_CHUNK, PT_AMD_REGEN_MIN, PT_AMD_IDLE_MIN, PT_AMD_PREFETCH, PT_AMD_TRACE); -1 / empty = not set
-    int knob_few_max = -1, knob_max_blocks = -1, knob_chunk = -1, knob_regen_min = -1, knob_idle_min = -1, knob_prefetch = -1;
+    int knob_few_max = -1, knob_max_blocks = -1, knob_chunk = -1, knob_regen_min = -1, knob_idle_min = -1, knob_prefetch = -1, knob_cap_pct = -1, knob_frames = -1;
     std::string knob_trace;
 };
 
@@ -130,6 +137,7 @@ int use(PtContext* ctx) {
 
 int join_chains(PtContext* ctx);
 int queue_next_fold(PtContext* ctx);
+int launch_pending(PtContext* ctx, bool joining = false);
 
 int alloc_frame(PtContext* ctx, uint32_t w, uint32_t h) {
     if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) return fail(PT_ERR_INVALID, "bad frame size %ux%u", w, h);
@@ -174,11 +182,13 @@ constexpr size_t WORK_SET_WORDS = 256;  // 8 shards x 32 words (128 B apart)
 int queue_next_fold(PtContext* ctx) {
     const uint32_t k = ctx->folds_queued, chain = k % ctx->flight;
     hipStream_t stream = ctx->chain_stream[chain];
+    const uint32_t npix = ctx->width * ctx->height, frames = ctx->chain_frames[chain];
     if (k > 0) PROF(ctx, 2, hipStreamWaitEvent(stream, ctx->fold_done[(k - 1u) % ctx->flight], 0));
-    PROF(ctx, 3, pt_launch_fold(ctx->accum, ctx->chain_acc[chain], ctx->fold_rgba[chain] ? (uint32_t*)ctx->display : nullptr,
-                                ctx->width * ctx->height, stream));
+    PROF(ctx, 3, pt_launch_fold(ctx->accum, ctx->chain_acc[chain], npix, frames, ctx->fold_rgba[chain] ? (uint32_t*)ctx->display : nullptr,
+                                ctx->history, npix, stream));
     PROF(ctx, 4, hipEventRecord(ctx->fold_done[chain], stream));
     ctx->display_current = ctx->fold_rgba[chain];
+    if (ctx->fold_rgba[chain]) ctx->history_frames = frames - 1u;
     ctx->folds_queued++;
     return PT_OK;
 }
@@ -187,6 +197,7 @@ int queue_next_fold(PtContext* ctx) {
 // that one is behind all others).  A no-op when no burst is open.  Nothing is left to add up: every
 // launch's sums are already in the accumulation buffer, in launch order.
 int join_chains(PtContext* ctx) {
+    if (int rc = launch_pending(ctx, true)) return rc;
     if (ctx->burst == 0) return PT_OK;
     while (ctx->folds_queued < ctx->burst)
         if (int rc = queue_next_fold(ctx)) return rc;
@@ -214,6 +225,18 @@ int switch_stream(PtContext* ctx, hipStream_t to) {
     return PT_OK;
 }
 
+// Most frames one overlapped launch may hold: at most 32, at most 2 GiB of sums per chain (2^27 pixel-frames, which
+// also keeps the kernel's ticket arithmetic below 2^23), and one when a frame side exceeds the 13 bits the kernel
+// packs x and y into beside the frame number.
+uint32_t frames_per_launch_max(const PtContext* ctx) {
+    if (ctx->width > 8192u || ctx->height > 8192u) return 1u;
+    const uint64_t npix = (uint64_t)ctx->width * ctx->height;
+    uint64_t fit = npix ? (1ull << 27) / npix : 1ull;
+    if (fit > 32u) fit = 32u;
+    if (ctx->knob_frames > 0 && fit > (uint64_t)ctx->knob_frames) fit = (uint64_t)ctx->knob_frames;  // PT_AMD_FRAMES
+    return fit < 1u ? 1u : (uint32_t)fit;
+}
+
 // Streams, events and buffers of the chains for the current frame size.
 int prepare_chains(PtContext* ctx) {
     const size_t npix = (size_t)ctx->width * ctx->height;
@@ -226,13 +249,18 @@ int prepare_chains(PtContext* ctx) {
         if (!ctx->chain_done[c]) HIP_TRY(hipEventCreateWithFlags(&ctx->chain_done[c], hipEventDisableTiming));
         if (!ctx->fold_done[c]) HIP_TRY(hipEventCreateWithFlags(&ctx->fold_done[c], hipEventDisableTiming));
     }
-    if (ctx->chain_acc_pixels != npix) {
+    const size_t planes = frames_per_launch_max(ctx);
+    if (ctx->chain_acc_pixels != npix || ctx->chain_planes != planes) {
         for (uint32_t c = 0; c < PT_MAX_CHAINS; ++c)
             if (ctx->chain_acc[c]) { HIP_TRY(hipFree(ctx->chain_acc[c])); ctx->chain_acc[c] = nullptr; }
+        if (ctx->history) { HIP_TRY(hipFree(ctx->history)); ctx->history = nullptr; }
         ctx->chain_acc_pixels = npix;
+        ctx->chain_planes = planes;
+        ctx->history_frames = 0;
     }
     for (uint32_t c = 0; c < ctx->flight; ++c)
-        if (!ctx->chain_acc[c]) HIP_TRY(hipMalloc((void**)&ctx->chain_acc[c], npix * sizeof(float4)));  // written whole by every launch
+        if (!ctx->chain_acc[c]) HIP_TRY(hipMalloc((void**)&ctx->chain_acc[c], planes * npix * sizeof(float4)));  // written whole by every launch
+    if (!ctx->history && planes > 1) HIP_TRY(hipMalloc((void**)&ctx->history, (planes - 1) * npix * sizeof(uint32_t)));
     return PT_OK;
 }
 
@@ -326,17 +354,19 @@ int render_in_parts(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count
     return rc;
 }
 
-// One launch of the path kernel for samples [sample_begin, sample_begin + sample_count) (arguments validated by pt_render).
-// `into` != nullptr is pt_render_noalloc's launch: one serial launch into the caller's buffer with the ticket counters
-// in the device's static scratch array; nothing on that path allocates, queries or creates anything.
-int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm, float4* into) {
+// One launch of the path kernel (arguments validated by pt_render): `frames` frames of sample_count samples each,
+// frame f = samples [sample_begin + f * sample_count, sample_begin + (f + 1) * sample_count).
+//  * pipelined: a launch of the open burst on the next chain; it writes one plane of sums per frame into the chain's
+//    buffer and the fold pass behind it adds them to the accumulation buffer in order.
+//  * otherwise (frames == 1): a serial launch on the context's stream that adds to the accumulation buffer itself.
+//    `into` != nullptr is pt_render_noalloc's launch: into the caller's buffer, with the ticket counters in the device's
+//    static scratch array; nothing on that path allocates, queries or creates anything.
+int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uint32_t frames, const PtRenderParams* prm,
+               float4* into, bool pipelined) {
     const bool noalloc = into != nullptr;
-    const bool pipelined = !noalloc && ctx->flight > 1 && can_overlap(ctx, prm);
     uint32_t chain = 0;
     hipStream_t stream = ctx->stream;
-    if (noalloc) {
-        // (pt_render_noalloc has checked that no burst is open)
-    } else if (pipelined) {
+    if (pipelined) {
         if (ctx->burst == 0) {
             if (int rc = prepare_chains(ctx)) return rc;
             HIP_TRY(hipEventRecord(ctx->fork_event, ctx->stream));
@@ -347,8 +377,6 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
         if (ctx->burst < ctx->flight) PROF(ctx, 0, hipStreamWaitEvent(stream, ctx->fork_event, 0));  // first launch of this chain in the burst
         while (ctx->burst >= ctx->flight && ctx->folds_queued + ctx->flight <= ctx->burst)
             if (int rc = queue_next_fold(ctx)) return rc;
-    } else {
-        if (int rc = join_chains(ctx)) return rc;
     }
     PathArgs a{};
     // A launch that overlaps others writes its own sums (sum_r, sum_g, sum_b, count) whole into its chain's buffer;
@@ -356,8 +384,12 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
     a.accum = noalloc ? into : (pipelined ? ctx->chain_acc[chain] : ctx->accum);
     a.overwrite = pipelined ? 1u : 0u;
     a.rgba = (prm->fused_rgba8 && !pipelined) ? (uint32_t*)ctx->display : nullptr;
+    if (a.rgba) ctx->history_frames = 0;  // (the display no longer continues the history planes)
     a.counters = (prm->flags & PT_FLAG_COUNTERS) ? ctx->counters : nullptr;
     a.s0 = sample_begin; a.count = sample_count;
+    a.frames = frames; a.plane_stride = ctx->width * ctx->height;
+    if (frames > 1u) { a.xw = 13u; a.yw = 13u; a.jo = 26u; a.jw = 6u; }   // (x, y, frame) of a lane's next ray in one register
+    else { a.xw = 16u; a.yw = 16u; a.jo = 0u; a.jw = 0u; }
     a.max_depth = prm->max_depth; a.rr_depth = prm->rr_depth; a.seed_hash = hash32(prm->seed);
     a.light_colour = (prm->flags & PT_FLAG_LIGHT_COLOUR) ? 1u : 0u;
     a.acc_mode = prm->acc_mode;
@@ -375,7 +407,7 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
         const uint32_t few = serial_cost / per_ray;
         a.few_max = few > 48u ? 48u : few;
         // (serial launches: 720p, 1 spp +15 % with it; 4K, 16 spp, 340 samples per resident lane, -3 %)
-        const uint64_t per_lane = ((uint64_t)ctx->width * ctx->height * sample_count) / ((uint64_t)ctx->compute_units * 6u * 256u);
+        const uint64_t per_lane = ((uint64_t)ctx->width * ctx->height * sample_count * frames) / ((uint64_t)ctx->compute_units * 6u * 256u);
         if ((pipelined || per_lane >= 100u) && a.few_max < 6u) a.few_max = 0u;
         if (ctx->knob_few_max >= 0) a.few_max = (uint32_t)ctx->knob_few_max;
     }
@@ -399,21 +431,22 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
     uint32_t cap = resident;
     if (pipelined) {
         const uint64_t weight = serial_cost > 400u ? serial_cost / 400u : 1u;
-        const uint64_t by_work = ((uint64_t)ctx->width * ctx->height * sample_count * weight) / (256u * 14u);
+        const uint64_t by_work = ((uint64_t)ctx->width * ctx->height * sample_count * frames * weight) / (256u * 14u);
         // (the factor is against 6 waves/SIMD: a build that fits 7 has the same optimum in blocks)
         const uint32_t six = ctx->compute_units * 6u;
         const uint32_t by_fill = ((resident < six ? resident : six) * 27u) / (20u * ctx->flight);
         const uint32_t want = by_work > by_fill ? (by_work > resident ? resident : (uint32_t)by_work) : by_fill;
         if (want < cap) cap = want;
+        if (ctx->knob_cap_pct > 0) { const uint64_t c = (uint64_t)want * (uint32_t)ctx->knob_cap_pct / 100u; cap = c > resident ? resident : (uint32_t)c; }
     }
     // work unit = 4x4 pixels; a ticket is at least units_per_grab of them.  Default: aim at >= 8
     // tickets per wave of the grid, but never more than one 8x8 tile per ticket -- two for launches of one
     // or two samples, where the atomics count (720p, 1 spp, 8 chains: 64 pixels per ticket 10.0, 128-256
     // 10.15, 384 and more 9.96 Gsamples/s; 4K, 16 spp: 64 pixels 11.73, 128 11.63).
-    const uint32_t units = a.num_tiles * 4u;
+    const uint32_t units = a.num_tiles * 4u * frames;
     uint32_t upg;
     if (prm->pixels_per_wave) upg = (prm->pixels_per_wave + 15u) / 16u;
-    else { const uint32_t most = sample_count <= 2u ? 8u : 4u; upg = units / (cap * 4u * 8u); upg = upg > most ? most : upg; }
+    else { const uint32_t most = frames > 1u ? 16u : (sample_count <= 2u ? 8u : 4u); upg = units / (cap * 4u * 8u); upg = upg > most ? most : upg; }
     a.units_per_grab = upg < 1u ? 1u : (upg > 65536u ? 65536u : upg);
     uint32_t blocks = (units / a.units_per_grab + 3u) / 4u;  // no more waves than tickets ...
     if (blocks > cap) blocks = cap;                          // ... and no more than the cap
@@ -430,7 +463,7 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
     if (sample_count == 1u) { const uint32_t r = 4800u / (serial_cost ? serial_cost : 1u); a.idle_min = r > 12u ? 12u : r; }
     // (launches that overlap others lose less to a withheld pixel -- another launch's lanes fill in: 720p, 16 spp, 8 in
     //  flight +3 % with it, `random4096` -7 %)
-    a.prefetch_pixels = ((uint64_t)ctx->width * ctx->height >= (uint64_t)cap * 256u * 8u || (pipelined && sample_count > 1u && serial_cost <= 800u)) ? 1u : 0u;
+    a.prefetch_pixels = ((uint64_t)ctx->width * ctx->height * frames >= (uint64_t)cap * 256u * 8u || (pipelined && sample_count > 1u && serial_cost <= 800u)) ? 1u : 0u;
     if (ctx->knob_regen_min >= 0) a.regen_min = (uint32_t)ctx->knob_regen_min;
     if (ctx->knob_idle_min >= 0) a.idle_min = (uint32_t)ctx->knob_idle_min;
     if (ctx->knob_prefetch >= 0) a.prefetch_pixels = (uint32_t)ctx->knob_prefetch;
@@ -463,7 +496,9 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
         a.trace = ctx->trace;
     } else a.trace = nullptr;
     PROF(ctx, 1, pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, few, blocks, stream));
+    ctx->path_launches++;
     if (pipelined) {
+        ctx->chain_frames[chain] = frames;
         ctx->fold_rgba[chain] = prm->fused_rgba8 != 0;   // its fold pass is enqueued later (queue_next_fold)
         if (prm->fused_rgba8) ctx->burst_displayed = true;
         ctx->burst++;
@@ -477,6 +512,41 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
     if (!noalloc) ctx->work_parity[chain] ^= 1u;
     ctx->last_acc_mode = prm->acc_mode;
     if (prm->fused_rgba8) ctx->display_bytes = (size_t)ctx->width * ctx->height * 4;
+    return PT_OK;
+}
+
+// Frames in flight: launches the frames collected so far as one launch of the burst.
+int launch_pending(PtContext* ctx, bool joining) {
+    if (ctx->pending.frames == 0) return PT_OK;
+    const PtContext::Pending p = ctx->pending;
+    ctx->pending.frames = 0;
+    // a single frame with nothing to overlap and nothing to follow (the caller flushes after every frame): the serial
+    // launch does the same sums without a fold pass behind it
+    if (joining && p.frames == 1u && ctx->burst == 0) return launch_now(ctx, p.begin, p.per_frame, 1u, &p.prm, nullptr, false);
+    return launch_now(ctx, p.begin, p.per_frame, p.frames, &p.prm, nullptr, true);
+}
+
+// One pt_render call (or one part of a large one).  With frames in flight the call is a FRAME of the next overlapped
+// launch: consecutive calls with the same parameters and sample count, each continuing where the one before it ended
+// (the reference's frame loop, main.cu:284-303, is exactly that), are collected and leave as one launch when
+// frames_per_launch_max() of them have gathered or anything needs their result (join_chains).  One launch over many
+// frames has one ramp and one tail instead of one per frame, hands out (frame, pixel) pairs instead of pixels -- at
+// 1280x720 a resident lane gets 2.3 pixels per frame -- and needs one fold pass, which still adds the frames one by one.
+int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm, float4* into) {
+    if (into) return launch_now(ctx, sample_begin, sample_count, 1u, prm, into, false);  // (pt_render_noalloc has checked that no burst is open)
+    if (!(ctx->flight > 1 && can_overlap(ctx, prm))) {
+        if (int rc = join_chains(ctx)) return rc;
+        return launch_now(ctx, sample_begin, sample_count, 1u, prm, nullptr, false);
+    }
+    PtContext::Pending& p = ctx->pending;
+    if (p.frames > 0 && !(sample_count == p.per_frame && sample_begin == p.begin + p.frames * p.per_frame &&
+                          memcmp(prm, &p.prm, sizeof(PtRenderParams)) == 0))
+        if (int rc = launch_pending(ctx)) return rc;
+    if (p.frames == 0) { p.begin = sample_begin; p.per_frame = sample_count; p.prm = *prm; }
+    p.frames++;
+    ctx->last_acc_mode = prm->acc_mode;
+    if (prm->fused_rgba8) ctx->display_bytes = (size_t)ctx->width * ctx->height * 4;
+    if (p.frames >= frames_per_launch_max(ctx)) return launch_pending(ctx);
     return PT_OK;
 }
 
@@ -511,6 +581,8 @@ int pt_create(int device_id, PtContext** out) {
     if (const char* e = getenv("PT_AMD_REGEN_MIN")) ctx->knob_regen_min = atoi(e);
     if (const char* e = getenv("PT_AMD_IDLE_MIN")) ctx->knob_idle_min = atoi(e);
     if (const char* e = getenv("PT_AMD_PREFETCH")) ctx->knob_prefetch = atoi(e);
+    if (const char* e = getenv("PT_AMD_CAP_PCT")) ctx->knob_cap_pct = atoi(e);
+    if (const char* e = getenv("PT_AMD_FRAMES")) ctx->knob_frames = atoi(e);
     if (const char* e = getenv("GPU_MAX_HW_QUEUES")) {  // HIP reads the same variable when it initialises
         const int q = atoi(e) - 4;
         ctx->burst_chains = q < 3 ? 3u : (q > (int)PT_MAX_CHAINS ? PT_MAX_CHAINS : (uint32_t)q);
@@ -548,6 +620,7 @@ int pt_destroy(PtContext* ctx) {
         if (ctx->chain_done[c]) (void)hipEventDestroy(ctx->chain_done[c]);
         if (ctx->fold_done[c]) (void)hipEventDestroy(ctx->fold_done[c]);
         if (ctx->chain_acc[c]) (void)hipFree(ctx->chain_acc[c]);
+        if (c == 0 && ctx->history) (void)hipFree(ctx->history);
     }
     if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
     if (ctx->trace) (void)hipFree(ctx->trace);
@@ -774,6 +847,7 @@ int pt_set_camera(PtContext* ctx, const PtCamera* c) {
         return fail(PT_ERR_INVALID, "the CPU camera divides by (width-1) and (height-1)");
     if (!(c->fov_deg > 0.0 && c->fov_deg < 180.0)) return fail(PT_ERR_INVALID, "fov must be in (0,180) degrees");
     if (c->use_dof && !(c->aperture >= 0.0 && c->focus_dist > 0.0)) return fail(PT_ERR_INVALID, "depth of field needs aperture >= 0 and focus_dist > 0");
+    if (int rc = launch_pending(ctx)) return rc;  // frames held back for the next overlapped launch belong to the old camera
     if (int rc = alloc_frame(ctx, c->width, c->height)) return rc;
 
     // ---- Camera_t::initialize (Camera.cu:3-23), float; initializeGPUData (raytracer_kernel.cu:308-321)
@@ -851,6 +925,7 @@ int pt_reset(PtContext* ctx) {
     if (!ctx->accum) return fail(PT_ERR_STATE, "no frame allocated");
     if (int rc = join_chains(ctx)) return rc;  // leaves the other chains' accumulators zero
     HIP_TRY(hipMemsetAsync(ctx->accum, 0, (size_t)ctx->width * ctx->height * sizeof(float4), ctx->stream));
+    ctx->history_frames = 0;
     return PT_OK;
 }
 
@@ -903,7 +978,7 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
     if (prm->max_depth == 0) return fail(PT_ERR_INVALID, "max_depth must be at least 1");
     if (prm->acc_mode == PT_ACC_RUNNING_MEAN && sample_count != 1)
         return fail(PT_ERR_INVALID, "the running-mean mode adds one sample per launch, like renderKernel");
-    if (ctx->burst != 0) return fail(PT_ERR_STATE, "frames are in flight: call pt_flush first (folding them launches on other streams)");
+    if (ctx->burst != 0 || ctx->pending.frames != 0) return fail(PT_ERR_STATE, "frames are in flight: call pt_flush first (folding them launches on other streams)");
     if (!ctx->scratch) return fail(PT_ERR_STATE, "the scratch array was not resolved at pt_create");
     return launch_path(ctx, sample_begin, sample_count, prm, (float4*)accum_float4);
 }
@@ -916,6 +991,7 @@ int pt_resolve(PtContext* ctx, uint32_t mode) {
     const uint32_t npix = ctx->width * ctx->height;
     HIP_TRY(pt_launch_resolve(ctx->accum, ctx->display, npix, ctx->last_acc_mode, mode, ctx->stream));
     ctx->display_bytes = (size_t)npix * (mode == PT_RESOLVE_FLOAT_MEAN ? 16 : mode == PT_RESOLVE_RGB8_PPM ? 3 : 4);
+    ctx->history_frames = 0;  // the display no longer continues the history planes
     return PT_OK;
 }
 
@@ -926,6 +1002,27 @@ int pt_readback(PtContext* ctx, void* host_dst, size_t bytes) {
     if (bytes > ctx->display_bytes) return fail(PT_ERR_INVALID, "asked for %zu bytes, display buffer holds %zu", bytes, ctx->display_bytes);
     if (int rc = join_chains(ctx)) return rc;
     HIP_TRY(hipMemcpyAsync(host_dst, ctx->display, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+uint32_t pt_history_frames(PtContext* ctx) {
+    pt_clear_error();
+    if (!ctx || join_chains(ctx) != PT_OK) return 0u;
+    return ctx->history_frames;
+}
+
+int pt_readback_history(PtContext* ctx, uint32_t frames_back, void* host_dst, size_t bytes) {
+    if (int rc = use(ctx)) return rc;
+    if (!host_dst) return fail(PT_ERR_INVALID, "host_dst is null");
+    if (int rc = join_chains(ctx)) return rc;
+    if (frames_back < 1u || frames_back > ctx->history_frames)
+        return fail(PT_ERR_STATE, "frame %u back is not held: the last fold pass displayed %u frames before its newest", frames_back, ctx->history_frames);
+    const size_t plane = (size_t)ctx->width * ctx->height * 4;
+    if (bytes > plane) return fail(PT_ERR_INVALID, "asked for %zu bytes, a picture holds %zu", bytes, plane);
+    // plane f of the history is frame f of the last launch folded; its newest frame (frames - 1) went to the display buffer
+    const uint8_t* src = (const uint8_t*)ctx->history + (size_t)(ctx->history_frames - frames_back) * plane;
+    HIP_TRY(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
@@ -968,6 +1065,11 @@ int pt_set_frames_in_flight(PtContext* ctx, uint32_t n) {
     // queues - 4 beyond it.  pt_frames_in_flight() tells the caller what it got.
     ctx->flight = n < ctx->burst_chains ? n : ctx->burst_chains;
     return PT_OK;
+}
+
+uint64_t pt_path_launches(PtContext* ctx) {
+    pt_clear_error();
+    return ctx ? ctx->path_launches : 0u;
 }
 
 uint32_t pt_frames_in_flight(PtContext* ctx) {

@@ -66,6 +66,12 @@ struct PathArgs {
     uint32_t regen_min;         // camera rays are prepared ahead in a batch once this many lanes lack one ...
     uint32_t idle_min;          // ... or once this many lanes sit idle for lack of one (or no lane traces)
     uint32_t prefetch_pixels;   // != 0: lanes take their next pixel while they still trace (launches with many pixels per lane)
+    // A launch of several FRAMES (frames in flight, pt_api.cpp): frame f holds samples [s0 + f*count, s0 + (f+1)*count) of
+    // every pixel and writes its sums to accum + f * plane_stride.  The work items are (frame, pixel) pairs from one
+    // ticket space, frame-major.  A lane keeps (x, y, frame) of its next ray packed in one register: x in bits
+    // [0, xw), y in [xw, xw + yw), frame in [jo, jo + jw); 16 / 16 / - for one frame, 13 / 13 / 6 for several.
+    uint32_t frames, plane_stride;
+    uint32_t xw, yw, jo, jw;
     uint64_t* trace;            // per-wave timeline, 16 x u64 per wave (PT_TRACE kernel builds only; else nullptr)
 };
 
@@ -106,10 +112,12 @@ hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArg
 hipError_t pt_path_resident_blocks(bool nee, bool count, bool few, int device, uint32_t* blocks);
 hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint32_t acc_mode, uint32_t mode,
                              hipStream_t stream);
-// frames in flight: adds the sums of one overlapped launch (its chain's buffer) to the accumulation buffer and,
-// with rgba != nullptr, makes the display from the new sums
+// frames in flight: adds the sums of the `frames` frames of one overlapped launch (planes of its chain's buffer,
+// plane_stride pixels apart) to the accumulation buffer, frame after frame; with newest != nullptr it makes every
+// frame's display on the way: the last frame's into `newest`, frame f < frames - 1 into history + f * npix
 constexpr uint32_t PT_MAX_CHAINS = 8;
-hipError_t pt_launch_fold(float4* accum, const float4* launch_sums, uint32_t* rgba, uint32_t npix, hipStream_t stream);
+hipError_t pt_launch_fold(float4* accum, const float4* planes, uint32_t plane_stride, uint32_t frames, uint32_t* newest,
+                          uint32_t* history, uint32_t npix, hipStream_t stream);
 hipError_t pt_launch_valu_peak(float* sink, uint32_t packed, uint32_t iters, uint32_t blocks, hipStream_t stream);
 hipError_t pt_launch_primary_ids(const DevSceneD& sc, const DevCamD& cam, uint32_t* obj, uint32_t* mat,
                                  hipStream_t stream);

@@ -31,9 +31,6 @@
 #ifndef PT_UPD
 #define PT_UPD 1
 #endif
-#ifndef PT_REGEN
-#define PT_REGEN 2
-#endif
 #ifndef PT_ONB
 #define PT_ONB 1
 #endif
@@ -437,7 +434,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
     const PathArgs& a = kargs.a;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t shard = blockIdx.x & 7u;
-    const uint32_t shard_units = ((a.num_tiles + 7u - shard) >> 3) * 4u;  // 4x4 blocks of the tiles = shard (mod 8)
+    const uint32_t shard_units = ((a.num_tiles + 7u - shard) >> 3) * 4u;  // 4x4 blocks of the tiles = shard (mod 8), per frame
     uint32_t unit0 = 0, pool_size = 0, pool_next = 0;  // wave-uniform; unit0 counts within the shard
     bool exhausted = false;                             // wave-uniform
     if (blockIdx.x == 0 && threadIdx.x < 8u) a.next_counter[threadIdx.x * 32u] = 0u;
@@ -451,21 +448,15 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
     __syncthreads();
 
     // lane state
-#if PT_REGEN == 2
     // The lane's CURRENT pixel (sum, prev, samples still to finish) and its NEXT camera ray, prepared ahead of time
     // (see the prepare step at the end of the loop body).
     bool cur_valid = false;          // owns a pixel whose sum is not flushed yet
-    uint32_t pixel = 0, cur_left = 0;
+    uint32_t pixel = 0, cur_left = 0;  // pixel: index into a.accum (frame * plane_stride + y * width + x)
     bool nx_valid = false;           // a prepared ray is waiting
-    uint32_t nx_pxy = 0;             // pixel of the prepared ray: x | y << 16
+    uint32_t nx_pxy = 0;             // pixel of the prepared ray: x | y << xw | frame << jo (PathArgs)
     uint32_t nx_si = 0xFFFFFFFFu;    // samples of that pixel generated so far (>= count: the lane needs a new pixel)
     uint32_t nx_key = 0;
     V3 nx_d = v3(0, 0, 1);
-#else
-    int my = -1;             // pool index of the pixel this lane owns, -1 = none
-    uint32_t pixel = 0, px = 0, py = 0, pixkey = 0;
-    uint32_t sample_i = 0;   // samples of `pixel` started so far
-#endif
     bool alive = false;      // a path is in flight
     V3 sum = v3(0, 0, 0);    // radiance sum of this pixel in this launch
     float4 prev = make_float4(0, 0, 0, 0);  // the pixel's accumulator, fetched when the pixel is taken
@@ -688,15 +679,10 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
                     if (!(NEE && shadow) && depth >= a.max_depth) end_path = true;
                 }
             }
-#if PT_REGEN == 2
             if (end_path) { sum = sum + L; alive = false; cur_left--; }
-#else
-            if (end_path) { sum = sum + L; alive = false; }
-#endif
         }
         PT_SECTION(_shade)
         }
-#if PT_REGEN == 2
         // ---- Regeneration, double-buffered.  A lane whose path ended wants a flush (rarely), and a new camera ray
         // (always): ~150 instructions that used to run on every trip at the 10-15 % of the lanes that had just
         // ended.  Now every lane holds its NEXT camera ray ready, so a path end costs a handful of moves (steps 1
@@ -750,23 +736,34 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
                     uint32_t ticket = 0;
                     if (lane == 0) ticket = atomicAdd(a.work_counter + shard * 32u, need);
                     ticket = __builtin_amdgcn_readfirstlane(ticket);
-                    if (ticket >= shard_units) {
+                    const uint32_t total_units = shard_units * kc->a.frames;  // a launch of several frames: frame-major
+                    if (ticket >= total_units) {
                         exhausted = true;
 #ifdef PT_TRACE
                         tr_exh = wall_clock64();
 #endif
                     } else {
                         unit0 = ticket;
-                        pool_size = min(need, shard_units - ticket) * 16u;
+                        pool_size = min(need, total_units - ticket) * 16u;
                         pool_next = 0;
                     }
                 }
                 if (!exhausted) {
                     const uint32_t cand = pool_next + lane_prefix(pull_mask);
                     if (want && cand < pool_size) {
-                        const uint32_t unit = unit0 + (cand >> 4), li = cand & 15u, q = unit & 3u;
+                        uint32_t unit = unit0 + (cand >> 4), frame = 0u;
+                        const uint32_t li = cand & 15u;
+                        // (integer divisions by wave-uniform numbers: float quotient + one fix-up instead of 25 instructions;
+                        //  the host keeps both dividends below 2^23)
+                        if (kc->a.frames > 1u) {  // wave-uniform: which frame of the launch, which unit of that frame
+                            frame = (uint32_t)(((float)unit + 0.5f) * (1.0f / (float)shard_units));
+                            int u = (int)(unit - frame * shard_units);
+                            if (u < 0) { u += (int)shard_units; frame--; }
+                            if (u >= (int)shard_units) { u -= (int)shard_units; frame++; }
+                            unit = (uint32_t)u;
+                        }
+                        const uint32_t q = unit & 3u;
                         const uint32_t tile = (unit >> 2) * 8u + shard;
-                        // tile / tiles_x without the 25-instruction integer division: float quotient + one fix-up
                         uint32_t ty = (uint32_t)(((float)tile + 0.5f) * a.inv_tiles_x);
                         int tx = (int)(tile - ty * a.tiles_x);
                         if (tx < 0) { tx += (int)a.tiles_x; ty--; }
@@ -774,7 +771,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
                         const uint32_t px = (uint32_t)tx * 8u + (q & 1u) * 4u + (li & 3u);
                         const uint32_t py = ty * 8u + (q >> 1) * 4u + (li >> 2);
                         if (px < a.width && py < a.height) {
-                            nx_pxy = px | (py << 16);
+                            nx_pxy = px | (py << kc->a.xw) | (frame << kc->a.jo);
                             nx_si = 0u;
                         }
                     }
@@ -783,14 +780,16 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
             }
             // ---- (2b) the camera ray of the pixel's next sample
             if (want_next && nx_si < a.count) {
-                const uint32_t pixkey = pt_hash(a.seed_hash + ((nx_pxy >> 16) * a.width + (nx_pxy & 0xFFFFu)));
-                nx_key = pt_hash(pixkey + (a.s0 + nx_si));
+                const uint32_t nx_x = __builtin_amdgcn_ubfe(nx_pxy, 0u, kc->a.xw), nx_y = __builtin_amdgcn_ubfe(nx_pxy, kc->a.xw, kc->a.yw);
+                const uint32_t pixkey = pt_hash(a.seed_hash + (nx_y * a.width + nx_x));
+                // frame f of the launch holds samples [s0 + f * count, s0 + (f + 1) * count)
+                nx_key = pt_hash(pixkey + (a.s0 + __builtin_amdgcn_ubfe(nx_pxy, kc->a.jo, kc->a.jw) * a.count + nx_si));
                 nx_si++;
                 // renderKernel :286-291 + generateCameraRay :245-265:
                 //   (2*(x + xi)/W - 1) * half_w  ==  (x + xi) * (2*half_w/W) - half_w
                 const PT_CONST DevCamF& cam = kc->cam;
-                const float xo = ((float)(nx_pxy & 0xFFFFu) + uni(pt_draw(nx_key, 0, 0))) * cam.sx - cam.half_w;
-                const float yo = ((float)(nx_pxy >> 16) + uni(pt_draw(nx_key, 0, 1))) * cam.sy - cam.half_h;
+                const float xo = ((float)nx_x + uni(pt_draw(nx_key, 0, 0))) * cam.sx - cam.half_w;
+                const float yo = ((float)nx_y + uni(pt_draw(nx_key, 0, 1))) * cam.sy - cam.half_h;
                 nx_d = v3(cam.fx + cam.rx * xo + cam.ux * yo, cam.fy + cam.ry * xo + cam.uy * yo, cam.fz + cam.rz * xo + cam.uz * yo);
                 if (!(cam.lens_radius > 0.0f)) nx_d = normalized(nx_d);  // (with a lens the direction is finished in step 3)
                 nx_valid = true;
@@ -801,7 +800,8 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
         if (!alive && nx_valid) {
             const PT_CONST DevCamF& cam = kc->cam;
             if (!cur_valid) {
-                pixel = (nx_pxy >> 16) * a.width + (nx_pxy & 0xFFFFu);
+                pixel = __builtin_amdgcn_ubfe(nx_pxy, kc->a.jo, kc->a.jw) * kc->a.plane_stride + __builtin_amdgcn_ubfe(nx_pxy, kc->a.xw, kc->a.yw) * a.width +
+                        __builtin_amdgcn_ubfe(nx_pxy, 0u, kc->a.xw);
                 if (need_prev) prev = a.accum[pixel];
                 sum = v3(0, 0, 0);
                 cur_left = a.count;
@@ -835,124 +835,6 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
         // done when nothing is in flight, prepared or unflushed, and the frame is exhausted
         if (__ballot(alive || nx_valid || cur_valid) == 0ull && exhausted) break;
     }
-#else
-        // Steps (1)-(3) run at the few lanes whose path just ended; executed on every trip they
-        // cost as many instructions as a third of an intersection at ~15 % lane occupancy.  They
-        // are therefore entered only when a.regen_min lanes have something to do there (or no
-        // lane is tracing), which trades a few idle lane-trips for fewer low-occupancy instructions.
-        const bool todo = !alive && (my >= 0 || !exhausted);
-        const uint64_t todo_mask = __ballot(todo);
-        const bool regen = (uint32_t)__popcll(todo_mask) >= a.regen_min || __ballot(alive) == 0ull;
-        if (regen) {
-        const PT_CONST KArgs* kc = cold();
-        // ---- (1) finished pixels are flushed: one 16-B store (the 16-B load was issued when the
-        //          pixel was taken, so its latency is long gone)
-        if (!alive && my >= 0 && sample_i == a.count) {
-            float4 acc;
-            if (a.acc_mode == 0u) {  // PT_ACC_SUM (prev is zero in a launch that writes its own sums whole)
-                acc = make_float4(prev.x + sum.x, prev.y + sum.y, prev.z + sum.z, prev.w + (float)a.count);
-            } else {  // PT_ACC_RUNNING_MEAN, renderKernel :297-304 (count == 1, s0 = frame_count)
-                acc = make_float4(sum.x, sum.y, sum.z, 1.0f);
-                if (a.s0 > 0u) {
-                    const float t = kc->a.mean_t;
-                    acc.x = sum.x * t + prev.x * (1.0f - t);
-                    acc.y = sum.y * t + prev.y * (1.0f - t);
-                    acc.z = sum.z * t + prev.z * (1.0f - t);
-                }
-            }
-            a.accum[pixel] = acc;
-            uint32_t* const rgba = kc->a.rgba;
-            if (rgba) {  // fused convertToRGBAKernel (launches that overlap others display in a pass of their own)
-                // every pixel normally holds the same count: its reciprocal comes from the host (same IEEE divide)
-                const float inv = (a.acc_mode != 0u) ? 1.0f : (acc.w == kc->a.total_w ? kc->a.inv_total_w : 1.0f / acc.w);
-                rgba[pixel] = pack_rgba8_cuda(acc.x * inv, acc.y * inv, acc.z * inv);
-            }
-            my = -1;
-        }
-        // ---- (2) lanes without a pixel pull the next one from the wave's pool; an empty pool is
-        //          refilled with one ticket from the global counter
-        const bool want = !alive && my < 0;
-        const uint64_t want_mask = __ballot(want);
-        if (want_mask != 0ull && !exhausted) {
-            if (pool_next >= pool_size) {
-                const uint32_t need = max(a.units_per_grab, ((uint32_t)__popcll(want_mask) + 15u) >> 4);
-                uint32_t ticket = 0;
-                if (lane == 0) ticket = atomicAdd(a.work_counter + shard * 32u, need);
-                ticket = __builtin_amdgcn_readfirstlane(ticket);
-                if (ticket >= shard_units) {
-                    exhausted = true;
-#ifdef PT_TRACE
-                    tr_exh = wall_clock64();
-#endif
-                } else {
-                    unit0 = ticket;
-                    pool_size = min(need, shard_units - ticket) * 16u;
-                    pool_next = 0;
-                }
-            }
-            if (!exhausted) {
-                const uint32_t cand = pool_next + lane_prefix(want_mask);
-                if (want && cand < pool_size) {
-                    const uint32_t unit = unit0 + (cand >> 4), li = cand & 15u, q = unit & 3u;
-                    const uint32_t tile = (unit >> 2) * 8u + shard;
-                    // tile / tiles_x without the 25-instruction integer division: float quotient + one fix-up
-                    uint32_t ty = (uint32_t)(((float)tile + 0.5f) * a.inv_tiles_x);
-                    int tx = (int)(tile - ty * a.tiles_x);
-                    if (tx < 0) { tx += (int)a.tiles_x; ty--; }
-                    if (tx >= (int)a.tiles_x) { tx -= (int)a.tiles_x; ty++; }
-                    px = (uint32_t)tx * 8u + (q & 1u) * 4u + (li & 3u);
-                    py = ty * 8u + (q >> 1) * 4u + (li >> 2);
-                    if (px < a.width && py < a.height) {
-                        my = (int)cand;
-                        pixel = py * a.width + px;
-                        pixkey = pt_hash(a.seed_hash + pixel);
-                        if (need_prev) prev = a.accum[pixel];
-                        sample_i = 0;
-                        sum = v3(0, 0, 0);
-                    }
-                }
-                pool_next = min(pool_next + (uint32_t)__popcll(want_mask), pool_size);
-            }
-        }
-        // ---- (3) start the next sample of the owned pixel
-        if (!alive && my >= 0 && sample_i < a.count) {
-            key = pt_hash(pixkey + (a.s0 + sample_i));
-            sample_i++;
-            // renderKernel :286-291 + generateCameraRay :245-265:
-            //   (2*(x + xi)/W - 1) * half_w  ==  (x + xi) * (2*half_w/W) - half_w
-            const PT_CONST DevCamF& cam = kc->cam;
-            const float xo = ((float)px + uni(pt_draw(key, 0, 0))) * cam.sx - cam.half_w;
-            const float yo = ((float)py + uni(pt_draw(key, 0, 1))) * cam.sy - cam.half_h;
-            o = v3(cam.ox, cam.oy, cam.oz);
-            d = v3(cam.fx + cam.rx * xo + cam.ux * yo, cam.fy + cam.ry * xo + cam.uy * yo, cam.fz + cam.rz * xo + cam.uz * yo);
-            const float lens_radius = cam.lens_radius;
-            if (lens_radius > 0.0f) {  // wave-uniform
-                // Depth of field, Camera_t::getRayDevice (Camera.cu:31-47): the virtual screen is at focus_dist
-                // (Camera.cu:15-19), the origin moves on the lens disk (randomInUnitDisk, :25-29) in the
-                // camera's right/up plane and the ray aims at the point the pinhole ray reaches on that screen.
-                const float r = fsqrt(uni(pt_draw(key, 0, 2))) * lens_radius;
-                const float th = uni(pt_draw(key, 0, 3));
-                const float lx = r * cos2pi(th), ly = r * sin2pi(th);
-                const V3 org = v3(o.x + cam.rx * lx + cam.ux * ly, o.y + cam.ry * lx + cam.uy * ly, o.z + cam.rz * lx + cam.uz * ly);
-                const float fd = cam.focus_dist;
-                d = v3(o.x + d.x * fd - org.x, o.y + d.y * fd - org.y, o.z + d.z * fd - org.z);
-                o = org;
-            }
-            d = normalized(d);
-            beta = v3(1, 1, 1);
-            L = v3(0, 0, 0);
-            depth = 0;
-            alive = true;
-            if (NEE) { shadow = false; prev_pdf_b = -1.0f; }
-            if (COUNT) c_samples++;
-        }
-        }  // regen
-        PT_SECTION(_regen)
-        // nothing in flight: done when no lane holds a pixel and the frame is exhausted; otherwise
-        // some lane flushes / pulls on the next trip
-        if (__ballot(alive) == 0ull && __ballot(my >= 0) == 0ull && exhausted) break;
-    }
-#endif
 
 #ifdef PT_TRACE
     if (a.trace && lane == 0) {
@@ -1013,24 +895,44 @@ __global__ __launch_bounds__(256) void pt_resolve_kernel(const float4* __restric
 }
 
 // ------------------------------------------------------------------------------------------
-// Frames in flight: the pass behind every overlapped launch.  The launch wrote its own sums whole into its chain's
-// buffer; this adds them to the accumulation buffer and, when asked, makes the display from the new sums
-// (convertToRGBAKernel, Window.cuh:16-30).  The passes of a context run on one stream in launch order, so the
-// buffer grows exactly as under serial launches -- acc += launch k, k = 0, 1, 2, ... -- and the frame shown after
-// launch k is the mean of samples 0..k, as in the reference's frame loop (main.cu:284-303).  HBM-bound: 16 B read +
-// 16 B read + 16 B written (+ 4 B) per pixel, beside path launches that are VALU-bound and leave HBM idle.
-__global__ __launch_bounds__(256) void pt_fold_kernel(float4* __restrict__ accum, const float4* __restrict__ sums,
-                                                      uint32_t* __restrict__ rgba, uint32_t npix) {
+// Frames in flight: the pass behind every overlapped launch.  The launch wrote the sums of each of its frames whole
+// into its chain's buffer (one plane per frame); this adds them to the accumulation buffer ONE FRAME AFTER THE OTHER
+// and, when asked, makes the display of every frame from the sums as they stand after it (convertToRGBAKernel,
+// Window.cuh:16-30).  The passes of a context run in launch order, so the buffer grows exactly as under serial
+// launches -- acc += frame k, k = 0, 1, 2, ... -- and the picture made for frame k is the mean of samples 0..k, as in
+// the reference's frame loop (main.cu:284-303): the newest goes to the display buffer, the ones before it to the
+// history planes (pt_download_display_history).  HBM-bound: per pixel 16 B read per frame, 16 B read + 16 B written
+// per pass, 4 B written per displayed frame, beside path launches that are VALU-bound and leave HBM idle.
+__device__ __forceinline__ void fold_frame(float4& a, const float4 q, uint32_t* dst) {
+    a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+    if (dst) {
+        const float inv = a.w > 0.0f ? 1.0f / a.w : 0.0f;
+        *dst = pack_rgba8_cuda(a.x * inv, a.y * inv, a.z * inv);
+    }
+}
+__global__ __launch_bounds__(256) void pt_fold_kernel(float4* __restrict__ accum, const float4* __restrict__ planes, uint32_t plane_stride,
+                                                      uint32_t frames, uint32_t* __restrict__ newest, uint32_t* __restrict__ history,
+                                                      uint32_t npix) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= npix) return;
     float4 a = accum[p];
-    const float4 q = sums[p];
-    a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
-    accum[p] = a;
-    if (rgba) {
-        const float inv = a.w > 0.0f ? 1.0f / a.w : 0.0f;
-        rgba[p] = pack_rgba8_cuda(a.x * inv, a.y * inv, a.z * inv);
+    const float4* q = planes + p;
+    // display of frame f: the last one into the display buffer, the others into history plane f (newest == nullptr: none)
+    uint32_t* h = newest ? history + p : nullptr;
+    uint32_t f = 0;
+    for (; f + 4u < frames; f += 4u) {  // four loads in flight; the last frame is always left to the tail below
+        const float4 q0 = q[0], q1 = q[plane_stride], q2 = q[2u * (size_t)plane_stride], q3 = q[3u * (size_t)plane_stride];
+        fold_frame(a, q0, h); fold_frame(a, q1, h ? h + npix : nullptr);
+        fold_frame(a, q2, h ? h + 2u * (size_t)npix : nullptr); fold_frame(a, q3, h ? h + 3u * (size_t)npix : nullptr);
+        q += 4u * (size_t)plane_stride;
+        if (h) h += 4u * (size_t)npix;
     }
+    for (; f < frames; ++f) {
+        fold_frame(a, *q, f + 1u == frames ? (newest ? newest + p : nullptr) : h);
+        q += plane_stride;
+        if (h) h += npix;
+    }
+    accum[p] = a;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1110,8 +1012,9 @@ hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint
     return hipGetLastError();
 }
 
-hipError_t pt_launch_fold(float4* accum, const float4* launch_sums, uint32_t* rgba, uint32_t npix, hipStream_t stream) {
-    hipLaunchKernelGGL(pt_fold_kernel, dim3((npix + 255) / 256), dim3(256), 0, stream, accum, launch_sums, rgba, npix);
+hipError_t pt_launch_fold(float4* accum, const float4* planes, uint32_t plane_stride, uint32_t frames, uint32_t* newest,
+                          uint32_t* history, uint32_t npix, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_fold_kernel, dim3((npix + 255u) / 256u), dim3(256), 0, stream, accum, planes, plane_stride, frames, newest, history, npix);
     return hipGetLastError();
 }
 

@@ -132,6 +132,20 @@ class Renderer:
         check(self._L.pt_readback(self._ctx, out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
 
+    def path_launches(self) -> int:
+        """Launches of the path kernel made so far (pt_path_launches)."""
+        return int(self._L.pt_path_launches(self._ctx))
+
+    def history_frames(self) -> int:
+        """Frames in flight: how many displays older than the newest the last fold pass left (pt_history_frames)."""
+        return int(self._L.pt_history_frames(self._ctx))
+
+    def readback_history(self, frames_back: int) -> np.ndarray:
+        """The RGBA8 display of the frame `frames_back` (>= 1) before the newest one (pt_readback_history)."""
+        out = np.empty((self.height, self.width), np.uint32)
+        check(self._L.pt_readback_history(self._ctx, int(frames_back), out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
     def resolve_to_host(self, mode: int) -> np.ndarray:
         self.resolve(mode)
         return self.readback(mode)

@@ -522,6 +522,110 @@ def test_frames_in_flight_match_serial(gpu, n):
         gpu.set_frames_in_flight(1)
 
 
+def test_frames_in_flight_make_every_frames_display(gpu):
+    """Frames in flight collect consecutive frames into one launch (up to 32) and fold them one by one: the display
+    of EVERY frame is made, from the sums as they stand after that frame -- the newest in the display buffer, the
+    ones before it in the history planes -- and each equals, byte for byte, the display the serial loop shows after
+    that frame (renderKernel + convertToRGBAKernel per frame, main.cu:284-303)."""
+    from path_tracer_amd._lib import PtError
+    sc, cam = scenes.cuda_default(192, 108)
+    p = abi.render_params(fused_rgba8=1)
+    frames = 41   # one launch of 32 frames and one of 9
+    _setup(gpu, sc, cam)
+    serial = []
+    for s in range(frames):
+        gpu.render(s, 1, p)
+        serial.append(gpu.readback(abi.RESOLVE_RGBA8_CUDA))
+    serial_acc = gpu.accum()
+    assert gpu.history_frames() == 0
+    gpu.set_frames_in_flight(3)
+    try:
+        _setup(gpu, sc, cam)
+        for s in range(11):
+            gpu.render(s, 1, p)
+        assert gpu.history_frames() == 10               # (joins: launches the 11 frames held back and folds them)
+        assert np.array_equal(gpu.readback(abi.RESOLVE_RGBA8_CUDA), serial[10])
+        for back in range(1, 11):
+            assert np.array_equal(gpu.readback_history(back), serial[10 - back]), back
+        with pytest.raises(PtError, match="not held"):
+            gpu.readback_history(11)
+        with pytest.raises(PtError, match="not held"):
+            gpu.readback_history(0)
+        for s in range(11, frames):                      # 30 more: the burst continues on the same buffer
+            gpu.render(s, 1, p)
+        assert np.array_equal(gpu.accum(), serial_acc)
+        assert np.array_equal(gpu.readback(abi.RESOLVE_RGBA8_CUDA), serial[frames - 1])
+        assert gpu.history_frames() == 29
+        for back in (1, 2, 15, 29):
+            assert np.array_equal(gpu.readback_history(back), serial[frames - 1 - back]), back
+        # more frames than one launch holds, in one go: 32 + 9; the history is the last fold pass's
+        _setup(gpu, sc, cam)
+        for s in range(frames):
+            gpu.render(s, 1, p)
+        assert np.array_equal(gpu.accum(), serial_acc)
+        assert gpu.history_frames() == 8
+        for back in range(1, 9):
+            assert np.array_equal(gpu.readback_history(back), serial[frames - 1 - back]), back
+        gpu.resolve(abi.RESOLVE_RGBA8_CUDA)              # anything else that writes the display ends the history
+        assert gpu.history_frames() == 0
+    finally:
+        gpu.set_frames_in_flight(1)
+
+
+def test_frames_in_flight_launch_boundaries(gpu):
+    """What may share a launch and what may not: frames whose parameters, sample count or sample range do not
+    continue the ones held back start a new launch, and a camera change launches what is held back with the old
+    camera.  Whatever the partition, the buffer is the serial loop's bit for bit."""
+    sc, cam = scenes.cuda_default(160, 90)
+    _, cam_b = scenes.glass_stress(160, 90)
+    calls = ([("render", s, 1, dict()) for s in range(5)] +                      # five frames of 1 spp
+             [("render", 5 + 3 * k, 3, dict()) for k in range(4)] +               # four of 3 spp
+             [("render", 17, 3, dict(max_depth=7)), ("render", 20, 3, dict(max_depth=7))] +  # other parameters
+             [("render", 40, 3, dict(max_depth=7))] +                             # a gap in the sample range
+             [("camera", cam_b)] +
+             [("render", 43 + k, 1, dict(fused_rgba8=1)) for k in range(6)] +      # another camera, with display
+             [("camera", cam)] +
+             [("render", 49 + 2 * k, 2, dict(flags=abi.FLAG_NEE_MIS)) for k in range(3)])
+    def run(r):
+        _setup(r, sc, cam)
+        for c in calls:
+            if c[0] == "camera":
+                r.set_camera(c[1])
+            else:
+                r.render(c[1], c[2], abi.render_params(**c[3]))
+        return r.accum()
+    want = run(gpu)
+    assert np.all(want[..., 3] == 5 + 12 + 6 + 3 + 6 + 6)
+    for n in (2, 3, 8):
+        gpu.set_frames_in_flight(n)
+        try:
+            got = run(gpu)
+        finally:
+            gpu.set_frames_in_flight(1)
+        assert np.array_equal(got, want), n
+
+
+def test_frames_in_flight_on_a_frame_wider_than_the_packed_coordinates(gpu):
+    """A lane keeps (x, y, frame) of its next ray in one register, 13 bits per coordinate when a launch holds several
+    frames; a frame wider or taller than 8192 gets one frame per launch (16 bits per coordinate) and still overlaps."""
+    sc, cam = scenes.cuda_default(8200, 8)
+    _setup(gpu, sc, cam)
+    for s in range(5):
+        gpu.render(s, 1, abi.render_params(max_depth=6, fused_rgba8=1))
+    want, want_rgba = gpu.accum(), gpu.readback(abi.RESOLVE_RGBA8_CUDA)
+    gpu.set_frames_in_flight(2)
+    try:
+        _setup(gpu, sc, cam)
+        for s in range(5):
+            gpu.render(s, 1, abi.render_params(max_depth=6, fused_rgba8=1))
+        assert np.array_equal(gpu.accum(), want)
+        assert np.array_equal(gpu.readback(abi.RESOLVE_RGBA8_CUDA), want_rgba)
+        assert gpu.history_frames() == 0
+    finally:
+        gpu.set_frames_in_flight(1)
+    _setup(gpu, *scenes.cuda_default(64, 36))   # (back to a small frame: the chains' buffers are resized with it)
+
+
 def test_frames_in_flight_cut_large_calls_into_launches(gpu):
     """With frames in flight one call for many samples per pixel is dealt to the chains in launches of
     ~32 samples (pt_api.cpp, pt_render): same samples, each once, whatever the call size."""

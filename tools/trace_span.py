@@ -1,11 +1,13 @@
 """rocprofv3 --kernel-trace CSV of a bench.py run -> the time per launch the bench line's roofline is quoted on.
 
-bench.py times its K launches with HIP events on the launch stream; with frames in flight the launches overlap, so
-rocprofv3's per-dispatch duration (start to end of ONE dispatch, other dispatches running beside it) is several times
-the time per launch.  The like-for-like figure from a trace is first start to last end of the K timed dispatches / K.
-Dispatch order of pt_path_kernel in a bench run: one set-up launch per chain, W warm-up, K timed, then (if frames in
-flight > 1) min(K, 128) strictly serial launches, then the instrumented launches (template argument COUNT = true,
-skipped here).  Fold passes (pt_fold_kernel) of the timed launches are inside the span.
+bench.py times its K frames with HIP events on the launch stream.  With frames in flight the library packs them into
+L launches of the path kernel (up to 32 frames each; the bench line says how many: roofline.launches) which overlap,
+so rocprofv3's per-dispatch duration (start to end of ONE dispatch, other dispatches running beside it) is up to
+`frames in flight` times the time per launch.  The like-for-like figure from a trace is first start to last end of
+the L timed dispatches / L.
+Dispatch order of pt_path_kernel in a one-leg bench run (--no-4k-leg): set-up, warm-up, the L timed launches, then (if
+frames in flight > 1) min(K, 128) strictly serial one-frame launches, then the instrumented launches (template
+argument COUNT = true, skipped here).  Fold passes (pt_fold_kernel) of the timed launches are inside the span.
 
   python tools/trace_span.py <kernel_trace.csv> <bench_line.json> <out.json> ["note"]
 """
@@ -20,18 +22,21 @@ path = [r for r in rows if "pt_path_kernel<" in r["Kernel_Name"] and not r["Kern
 path.sort(key=lambda r: int(r["Start_Timestamp"]))
 fold = sorted((r for r in rows if "pt_fold_kernel" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
 st = [int(r["Start_Timestamp"]) for r in path]; en = [int(r["End_Timestamp"]) for r in path]
-timed = range(F + W, F + W + K)
+L = int(d["roofline"]["launches"])
+n_serial = min(K, 128) if F > 1 else 0
+timed = range(len(path) - n_serial - L, len(path) - n_serial)
 first, last = min(st[i] for i in timed), max(en[i] for i in timed)
 folds_in = [r for r in fold if first <= int(r["Start_Timestamp"]) and int(r["Start_Timestamp"]) <= last + 200000]
 last_fold = max([int(r["End_Timestamp"]) for r in folds_in] + [last])
 busy = sum(en[i] - st[i] for i in timed)
-res = {"source": note, "timed_launches": K, "warmup": W, "frames_in_flight": F,
-       "first_start_to_last_end_ns": last - first, "ns_per_launch_amortised": (last - first) / K,
-       "first_start_to_last_fold_end_ns": last_fold - first, "ns_per_launch_incl_last_fold": (last_fold - first) / K,
-       "mean_dispatch_duration_ns": busy / K, "mean_launches_in_flight": busy / (last - first),
+res = {"source": note, "timed_frames": K, "timed_launches": L, "frames_per_launch": K / L, "warmup": W, "frames_in_flight": F,
+       "first_start_to_last_end_ns": last - first, "ns_per_launch_amortised": (last - first) / L,
+       "first_start_to_last_fold_end_ns": last_fold - first, "ns_per_launch_incl_last_fold": (last_fold - first) / L,
+       "ns_per_frame_incl_last_fold": (last_fold - first) / K,
+       "mean_dispatch_duration_ns": busy / L, "mean_launches_in_flight": busy / (last - first),
        "fold_passes_in_span": len(folds_in), "mean_fold_duration_ns": (sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in folds_in) / max(len(folds_in), 1))}
-ser = range(F + W + K, len(path))
-if F > 1 and len(ser) > 0:
+ser = range(len(path) - n_serial, len(path))
+if len(ser) > 0:
     res["serial_launches"] = len(ser)
     res["serial_ns_per_launch"] = (max(en[i] for i in ser) - min(st[i] for i in ser)) / len(ser)
     res["serial_mean_dispatch_duration_ns"] = sum(en[i] - st[i] for i in ser) / len(ser)
@@ -39,6 +44,7 @@ r = d["roofline"]
 res["bench_line_of_the_same_run"] = {"value_msamples_per_s": d["value"], "ms_per_step": d["ms_per_step"], "kernel_ms": r["kernel_ms"],
                                      "kernel_ms_serial": r.get("kernel_ms_serial"), "frac": r["frac"], "flops_per_launch": r["flops_per_launch"]}
 res["frac_from_this_trace"] = r["flops_per_launch"] / (res["ns_per_launch_incl_last_fold"] * 1e-9) / 1e12 / r["peak"]
+res["frac_path_kernels_only"] = r["flops_per_launch"] / (res["ns_per_launch_amortised"] * 1e-9) / 1e12 / r["peak"]
 res["frac_line_over_trace"] = r["frac"] / res["frac_from_this_trace"]
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))
