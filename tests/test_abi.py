@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "pt.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+char\s*\*|int|void\s*\*|void|uint32_t)\s+(\w+)\s*\(", text, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+char\s*\*|int|void\s*\*|void|uint32_t|uint64_t)\s+(\w+)\s*\(", text, flags=re.M)
     return sorted(set(names))
 
 
