@@ -119,8 +119,8 @@ struct PtContext {
     size_t trace_waves = 0;
     uint32_t resident_blocks[8] = {};  // per kernel build (nee, count, few)
     // tuning / tracing knobs for tools/gpu_ab.py and tools/gpu_trace.py, read once at pt_create
-    // (PT_AMD_FEW_MAX, PT_AMD_MAX_BLOCKS, PT_AMD_CHUNK, PT_AMD_REGEN_MIN, PT_AMD_IDLE_MIN, PT_AMD_PREFETCH, PT_AMD_TRACE); -1 / empty = not set
-    int knob_few_max = -1, knob_max_blocks = -1, knob_chunk = -1, knob_regen_min = -1, knob_idle_min = -1, knob_prefetch = -1, knob_cap_pct = -1, knob_frames = -1;
+    // (PT_AMD_FEW_MAX, PT_AMD_MAX_BLOCKS, PT_AMD_GRID_PCT, PT_AMD_FRAMES, PT_AMD_CHUNK, PT_AMD_REGEN_MIN, PT_AMD_IDLE_MIN, PT_AMD_PREFETCH, PT_AMD_TRACE); -1 / empty = not set
+    int knob_few_max = -1, knob_max_blocks = -1, knob_chunk = -1, knob_regen_min = -1, knob_idle_min = -1, knob_prefetch = -1, knob_grid_pct = -1, knob_frames = -1;
     std::string knob_trace;
 };
 
@@ -403,9 +403,16 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     const DevSceneF& f = ctx->sf;
     const uint32_t serial_cost = 25u * (uint32_t)f.ns + 7u * (uint32_t)(f.nax + f.nay + f.naz) + 13u * (uint32_t)f.npg + 35u * (uint32_t)f.nt;
     {
-        const uint32_t per_ray = 40u + 27u * (((uint32_t)f.ns + 63u) / 64u) + 15u * (((uint32_t)f.np + 63u) / 64u) + 37u * (((uint32_t)f.nt + 63u) / 64u);
+        // per ray in the lane-parallel form: the broadcast and the reduction, one test per 64 primitives of a kind, and
+        // the wait for every 64 beyond the first of a kind, which come from global memory instead of LDS with no other
+        // work to hide the load behind (fitted on tools/heuristics_sweep.py: best threshold 3 / 14 / 28 / 30 rays at
+        // 19 / 150 / 1000 / 4097 primitives; the first model, without the waits, gave 3 / 27 / 48 / 48 and lost 25 %
+        // at 150 primitives, where 24 rays already cost more than one pass of the serial loop)
+        const uint32_t cs = ((uint32_t)f.ns + 63u) / 64u, cp = ((uint32_t)f.np + 63u) / 64u, ct = ((uint32_t)f.nt + 63u) / 64u;
+        const uint32_t from_global = (cs > 1u ? cs - 1u : 0u) + (cp > 1u ? cp - 1u : 0u) + (ct > 1u ? ct - 1u : 0u);
+        const uint32_t per_ray = 40u + 27u * cs + 15u * cp + 37u * ct + 60u * (from_global < 2u ? from_global : 2u) + 25u * (from_global > 2u ? from_global - 2u : 0u);
         const uint32_t few = serial_cost / per_ray;
-        a.few_max = few > 48u ? 48u : few;
+        a.few_max = few > 32u ? 32u : few;
         // (serial launches: 720p, 1 spp +15 % with it; 4K, 16 spp, 340 samples per resident lane, -3 %)
         const uint64_t per_lane = ((uint64_t)ctx->width * ctx->height * sample_count * frames) / ((uint64_t)ctx->compute_units * 6u * 256u);
         if ((pipelined || per_lane >= 100u) && a.few_max < 6u) a.few_max = 0u;
@@ -437,7 +444,6 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
         const uint32_t by_fill = ((resident < six ? resident : six) * 27u) / (20u * ctx->flight);
         const uint32_t want = by_work > by_fill ? (by_work > resident ? resident : (uint32_t)by_work) : by_fill;
         if (want < cap) cap = want;
-        if (ctx->knob_cap_pct > 0) { const uint64_t c = (uint64_t)want * (uint32_t)ctx->knob_cap_pct / 100u; cap = c > resident ? resident : (uint32_t)c; }
     }
     // work unit = 4x4 pixels; a ticket is at least units_per_grab of them.  Default: aim at >= 8
     // tickets per wave of the grid, but never more than one 8x8 tile per ticket -- two for launches of one
@@ -470,6 +476,7 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     if (a.regen_min < 1u) a.regen_min = 1u;
     if (a.idle_min < 1u) a.idle_min = 1u;
     if (ctx->knob_max_blocks > 0 && blocks > (uint32_t)ctx->knob_max_blocks) blocks = (uint32_t)ctx->knob_max_blocks;
+    if (ctx->knob_grid_pct > 0) blocks = (uint32_t)((uint64_t)blocks * (uint32_t)ctx->knob_grid_pct / 100u);  // PT_AMD_GRID_PCT: the sweep of tests/ and tools/
     if (blocks < 8u) blocks = 8u;                            // every shard needs a block to serve its tiles
     // launches of one chain are ordered on its stream (chain 0 also serves unpipelined launches, which
     // join_chains() orders after it): each zeroes the set its successor on the same chain will use
@@ -581,7 +588,7 @@ int pt_create(int device_id, PtContext** out) {
     if (const char* e = getenv("PT_AMD_REGEN_MIN")) ctx->knob_regen_min = atoi(e);
     if (const char* e = getenv("PT_AMD_IDLE_MIN")) ctx->knob_idle_min = atoi(e);
     if (const char* e = getenv("PT_AMD_PREFETCH")) ctx->knob_prefetch = atoi(e);
-    if (const char* e = getenv("PT_AMD_CAP_PCT")) ctx->knob_cap_pct = atoi(e);
+    if (const char* e = getenv("PT_AMD_GRID_PCT")) ctx->knob_grid_pct = atoi(e);
     if (const char* e = getenv("PT_AMD_FRAMES")) ctx->knob_frames = atoi(e);
     if (const char* e = getenv("GPU_MAX_HW_QUEUES")) {  // HIP reads the same variable when it initialises
         const int q = atoi(e) - 4;
