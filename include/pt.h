@@ -282,18 +282,21 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
  * (472 MB at 1280x720, at most 2 GiB), plus 4 B per pixel and frame for the
  * display history (one per context).
  *
- * Large calls.  A pixel belongs to one lane per launch, so one long launch over
- * few pixels per lane (2.3 at 1280x720) ends with most lanes idle.  On frames
- * of at most 2^22 pixels a PT_ACC_SUM path call is therefore executed as several
- * launches of 8..32 samples on the internal streams: with n > 1, calls for more
- * than 48 samples join the open burst; with n = 1, a call for 12 samples or
- * more is a burst of its own on three chains (GPU_MAX_HW_QUEUES - 4 of them
- * when the environment grants more, up to 8), folded (and, with fused_rgba8,
- * displayed) before pt_render returns, so nothing stays in flight.  The partition
- * depends only on the call's arguments: the image is reproducible and equals
- * the single launch's up to float summation order (the launches' sums are added
- * one after the other instead of sample by sample).  (Environment variable
- * PT_AMD_CHUNK=0, read at pt_create, keeps every call one launch.) */
+ * Large calls.  Within a frame a pixel's samples belong to one lane, so one launch
+ * with many samples per pixel over few pixels per lane (2.3 at 1280x720) ends with
+ * most lanes idle.  On frames of at most 2^22 pixels a PT_ACC_SUM path call for 4
+ * samples or more is therefore rendered as FRAMES of 1..4 samples (32 frames for
+ * up to 128 samples, 4 samples per frame beyond) of multi-frame launches: with
+ * n > 1 they join the open burst like any other frame; with n = 1 the call is a
+ * burst of its own on three chains (GPU_MAX_HW_QUEUES - 4 of them when the
+ * environment grants more, up to 8), folded (and, with fused_rgba8, displayed)
+ * before pt_render returns, so nothing stays in flight.  The cut depends only on
+ * the call's arguments and the frame size: the image is reproducible, the same
+ * bit for bit for every n, and equals the single launch's up to float summation
+ * order (the frames' sums are added one after the other instead of sample by
+ * sample; with one sample per frame that IS the reference's progressive order,
+ * main.cu:284-303).  (Environment variable PT_AMD_CHUNK=0, read at pt_create,
+ * keeps every call one launch.) */
 int pt_set_frames_in_flight(PtContext* ctx, uint32_t n);
 uint32_t pt_frames_in_flight(PtContext* ctx);
 /* Launches of the path kernel this context has made so far (frames that are held

@@ -299,26 +299,28 @@ bool can_overlap(const PtContext* ctx, const PtRenderParams* prm) {
     return prm->acc_mode == PT_ACC_SUM && ctx->knob_trace.empty();
 }
 
-// Samples per launch when a call is cut into launches (0: never cut).
-uint32_t part_size(const PtContext* ctx, uint32_t sample_count, bool pipelined) {
+// Samples per frame when a call for several samples is cut into frames of a multi-frame launch (0: never cut).
+// A pixel's samples within a frame belong to one lane; frames of one or two samples make (frame, pixel) items small
+// enough to balance the lanes at the end of the launch, and 32 frames fill a launch.  Measured at 1280x720, one
+// call, Gsamples/s by samples per frame (tools/chunk_sweep.py):  16 spp: 1: 9.6, 2: 9.4, 4: 8.9, 8: 7.9, whole: 5.8;
+// 64 spp: 1-3: 11.8, 8: 11.2, 32: 8.6;  256 spp: 1: 12.2, 2-8: 12.5, 32: 11.7, whole: 6.3.
+uint32_t part_size(const PtContext* ctx, uint32_t sample_count) {
     if (ctx->knob_chunk >= 0) return (uint32_t)ctx->knob_chunk;
-    if (pipelined) return 32u;
-    // a burst of its own wants about four launches per chain to amortise its tail (8..32 samples each)
-    const uint32_t c = (sample_count + 11u) / 12u;
-    return c < 8u ? 8u : (c > 32u ? 32u : c);
+    const uint32_t c = (sample_count + 31u) / 32u;
+    return c < 1u ? 1u : (c > 4u ? 4u : c);
 }
 
-// A pixel belongs to one lane for the whole launch, so a launch with many samples per pixel and few pixels
-// per lane (2.3 at 720p) ends with most lanes idle while the last pixels finish: one 256-sample launch at
-// 720p runs at 6.1 Gsamples/s, the same samples in 32-sample launches dealt to the chains at 10.  A call for
-// more than 48 samples (12 without frames in flight: three chains at 4 samples per launch already beat one
-// serial launch, 9.6 against 5.9 Gsamples/s) is therefore cut into such launches.  4K launches hold 21
-// pixels per lane and are left whole.
+// A pixel belongs to one lane for the whole launch, so one launch with many samples per pixel and few pixels per
+// lane (2.3 at 720p) ends with most lanes idle while the last pixels finish.  On frames of at most 2^22 pixels a
+// PT_ACC_SUM path call for several samples is therefore rendered as frames of 1..4 samples (4K launches hold 21
+// pixels per lane and are left whole), from 4 samples on (below that one serial launch is as fast).  With frames in
+// flight those frames join the open burst like any other; a call made without is a burst of its own.  The cut
+// depends on the call's arguments and the frame size only -- not on the frames in flight -- so the image is
+// the same bit for bit either way.
 bool wants_parts(const PtContext* ctx, uint32_t sample_count, const PtRenderParams* prm) {
     if (!can_overlap(ctx, prm) || (uint64_t)ctx->width * ctx->height > (1ull << 22)) return false;
-    const bool pipelined = ctx->flight > 1;
-    const uint32_t part = part_size(ctx, sample_count, pipelined);
-    return part > 0 && sample_count >= (pipelined ? part + part / 2u + 1u : 12u);
+    const uint32_t part = part_size(ctx, sample_count);
+    return part > 0 && sample_count > part && sample_count >= 4u;
 }
 
 int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm, float4* into = nullptr);
@@ -329,9 +331,8 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
 // summation order.
 int render_in_parts(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm) {
     const bool pipelined = ctx->flight > 1;
-    const uint32_t part = part_size(ctx, sample_count, pipelined);
-    uint32_t parts = (sample_count + part - 1u) / part;
-    if (!pipelined && parts < 3u) parts = 3u;  // one launch per chain at least
+    const uint32_t part = part_size(ctx, sample_count);
+    const uint32_t parts = (sample_count + part - 1u) / part;
     const uint32_t user_flight = ctx->flight;
     PtRenderParams sub = *prm;
     if (!pipelined) {
