@@ -244,9 +244,10 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
  * serialises launch and display, one frame at a time; there is no counterpart.
  * With n > 1 a PT_ACC_SUM path call is a FRAME that the library may hold back and
  * overlap with others:
- *  - Consecutive calls with the same parameters and sample count, each starting at
- *    the sample where the one before it ended (the reference's loop is exactly
- *    that), are collected -- up to 32 of them, fewer on frames beyond 4 Mpixel
+ *  - Consecutive calls with the same parameters and sample count whose sample
+ *    ranges are equally spaced -- each starting where the one before it ended (the
+ *    reference's loop is exactly that), or a fixed distance further on (a rank of a
+ *    sample-split render takes its slice of every step) -- are collected -- up to 32 of them, fewer on frames beyond 4 Mpixel
  *    (2^27 pixel-frames per launch), one on frames wider or taller than 8192 -- and
  *    leave as ONE launch of the path kernel when that many have gathered or when
  *    anything needs their result.  The launch hands out (frame, pixel) pairs from one

@@ -107,7 +107,7 @@ struct PtContext {
     uint32_t* history = nullptr;       // displays of the frames before the newest of the last fold pass, one plane each
     uint32_t history_frames = 0;       // planes of `history` that hold a picture (frame history_frames-1 is the newest but one)
     // Frames collected for the next overlapped launch (pt_render calls that were accepted but not launched yet)
-    struct Pending { uint32_t begin = 0, per_frame = 0, frames = 0; PtRenderParams prm{}; } pending;
+    struct Pending { uint32_t begin = 0, per_frame = 0, stride = 0, frames = 0; PtRenderParams prm{}; } pending;
     uint32_t burst = 0;                // launches since the chains were last joined
     uint64_t path_launches = 0;        // launches of the path kernel since pt_create (pt_path_launches)
     bool burst_displayed = false;      // some launch of the burst asked for a display
@@ -356,14 +356,14 @@ int render_in_parts(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count
 }
 
 // One launch of the path kernel (arguments validated by pt_render): `frames` frames of sample_count samples each,
-// frame f = samples [sample_begin + f * sample_count, sample_begin + (f + 1) * sample_count).
+// frame f = samples [sample_begin + f * frame_stride, sample_begin + f * frame_stride + sample_count).
 //  * pipelined: a launch of the open burst on the next chain; it writes one plane of sums per frame into the chain's
 //    buffer and the fold pass behind it adds them to the accumulation buffer in order.
 //  * otherwise (frames == 1): a serial launch on the context's stream that adds to the accumulation buffer itself.
 //    `into` != nullptr is pt_render_noalloc's launch: into the caller's buffer, with the ticket counters in the device's
 //    static scratch array; nothing on that path allocates, queries or creates anything.
-int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uint32_t frames, const PtRenderParams* prm,
-               float4* into, bool pipelined) {
+int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uint32_t frames, uint32_t frame_stride,
+               const PtRenderParams* prm, float4* into, bool pipelined) {
     const bool noalloc = into != nullptr;
     uint32_t chain = 0;
     hipStream_t stream = ctx->stream;
@@ -388,7 +388,7 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     if (a.rgba) ctx->history_frames = 0;  // (the display no longer continues the history planes)
     a.counters = (prm->flags & PT_FLAG_COUNTERS) ? ctx->counters : nullptr;
     a.s0 = sample_begin; a.count = sample_count;
-    a.frames = frames; a.plane_stride = ctx->width * ctx->height;
+    a.frames = frames; a.plane_stride = ctx->width * ctx->height; a.frame_stride = frame_stride;
     if (frames > 1u) { a.xw = 13u; a.yw = 13u; a.jo = 26u; a.jw = 6u; }   // (x, y, frame) of a lane's next ray in one register
     else { a.xw = 16u; a.yw = 16u; a.jo = 0u; a.jw = 0u; }
     a.max_depth = prm->max_depth; a.rr_depth = prm->rr_depth; a.seed_hash = hash32(prm->seed);
@@ -530,8 +530,8 @@ int launch_pending(PtContext* ctx, bool joining) {
     ctx->pending.frames = 0;
     // a single frame with nothing to overlap and nothing to follow (the caller flushes after every frame): the serial
     // launch does the same sums without a fold pass behind it
-    if (joining && p.frames == 1u && ctx->burst == 0) return launch_now(ctx, p.begin, p.per_frame, 1u, &p.prm, nullptr, false);
-    return launch_now(ctx, p.begin, p.per_frame, p.frames, &p.prm, nullptr, true);
+    if (joining && p.frames == 1u && ctx->burst == 0) return launch_now(ctx, p.begin, p.per_frame, 1u, p.per_frame, &p.prm, nullptr, false);
+    return launch_now(ctx, p.begin, p.per_frame, p.frames, p.frames > 1u ? p.stride : p.per_frame, &p.prm, nullptr, true);
 }
 
 // One pt_render call (or one part of a large one).  With frames in flight the call is a FRAME of the next overlapped
@@ -541,16 +541,27 @@ int launch_pending(PtContext* ctx, bool joining) {
 // frames has one ramp and one tail instead of one per frame, hands out (frame, pixel) pairs instead of pixels -- at
 // 1280x720 a resident lane gets 2.3 pixels per frame -- and needs one fold pass, which still adds the frames one by one.
 int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm, float4* into) {
-    if (into) return launch_now(ctx, sample_begin, sample_count, 1u, prm, into, false);  // (pt_render_noalloc has checked that no burst is open)
+    if (into) return launch_now(ctx, sample_begin, sample_count, 1u, sample_count, prm, into, false);  // (pt_render_noalloc has checked that no burst is open)
     if (!(ctx->flight > 1 && can_overlap(ctx, prm))) {
         if (int rc = join_chains(ctx)) return rc;
-        return launch_now(ctx, sample_begin, sample_count, 1u, prm, nullptr, false);
+        return launch_now(ctx, sample_begin, sample_count, 1u, sample_count, prm, nullptr, false);
     }
+    // The frames of a launch are equally long and equally far apart: the second frame fixes the distance (the sample
+    // count for one process; a multiple of it when the samples of every step are divided among GPUs, each rank
+    // rendering the r-th slice of every step, path_tracer_amd/distributed.py).
     PtContext::Pending& p = ctx->pending;
-    if (p.frames > 0 && !(sample_count == p.per_frame && sample_begin == p.begin + p.frames * p.per_frame &&
-                          memcmp(prm, &p.prm, sizeof(PtRenderParams)) == 0))
-        if (int rc = launch_pending(ctx)) return rc;
-    if (p.frames == 0) { p.begin = sample_begin; p.per_frame = sample_count; p.prm = *prm; }
+    if (p.frames > 0) {
+        bool fits = sample_count == p.per_frame && memcmp(prm, &p.prm, sizeof(PtRenderParams)) == 0;
+        if (fits && p.frames == 1u) {
+            fits = sample_begin >= p.begin + p.per_frame;   // (no overlap; a wrapped range is not collected either)
+            if (fits) p.stride = sample_begin - p.begin;
+        } else if (fits) {
+            fits = sample_begin == p.begin + p.frames * p.stride;
+        }
+        if (!fits)
+            if (int rc = launch_pending(ctx)) return rc;
+    }
+    if (p.frames == 0) { p.begin = sample_begin; p.per_frame = sample_count; p.stride = sample_count; p.prm = *prm; }
     p.frames++;
     ctx->last_acc_mode = prm->acc_mode;
     if (prm->fused_rgba8) ctx->display_bytes = (size_t)ctx->width * ctx->height * 4;

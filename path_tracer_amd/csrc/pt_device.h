@@ -66,11 +66,12 @@ struct PathArgs {
     uint32_t regen_min;         // camera rays are prepared ahead in a batch once this many lanes lack one ...
     uint32_t idle_min;          // ... or once this many lanes sit idle for lack of one (or no lane traces)
     uint32_t prefetch_pixels;   // != 0: lanes take their next pixel while they still trace (launches with many pixels per lane)
-    // A launch of several FRAMES (frames in flight, pt_api.cpp): frame f holds samples [s0 + f*count, s0 + (f+1)*count) of
-    // every pixel and writes its sums to accum + f * plane_stride.  The work items are (frame, pixel) pairs from one
+    // A launch of several FRAMES (frames in flight, pt_api.cpp): frame f holds samples [s0 + f*frame_stride, ... + count)
+    // of every pixel (frame_stride = count for one process; count * ranks when the samples of a step are split among
+    // GPUs) and writes its sums to accum + f * plane_stride.  The work items are (frame, pixel) pairs from one
     // ticket space, frame-major.  A lane keeps (x, y, frame) of its next ray packed in one register: x in bits
     // [0, xw), y in [xw, xw + yw), frame in [jo, jo + jw); 16 / 16 / - for one frame, 13 / 13 / 6 for several.
-    uint32_t frames, plane_stride;
+    uint32_t frames, plane_stride, frame_stride;
     uint32_t xw, yw, jo, jw;
     uint64_t* trace;            // per-wave timeline, 16 x u64 per wave (PT_TRACE kernel builds only; else nullptr)
 };

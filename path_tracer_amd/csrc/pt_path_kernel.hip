@@ -782,8 +782,8 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
             if (want_next && nx_si < a.count) {
                 const uint32_t nx_x = __builtin_amdgcn_ubfe(nx_pxy, 0u, kc->a.xw), nx_y = __builtin_amdgcn_ubfe(nx_pxy, kc->a.xw, kc->a.yw);
                 const uint32_t pixkey = pt_hash(a.seed_hash + (nx_y * a.width + nx_x));
-                // frame f of the launch holds samples [s0 + f * count, s0 + (f + 1) * count)
-                nx_key = pt_hash(pixkey + (a.s0 + __builtin_amdgcn_ubfe(nx_pxy, kc->a.jo, kc->a.jw) * a.count + nx_si));
+                // frame f of the launch holds samples [s0 + f * frame_stride, s0 + f * frame_stride + count)
+                nx_key = pt_hash(pixkey + (a.s0 + __builtin_amdgcn_ubfe(nx_pxy, kc->a.jo, kc->a.jw) * kc->a.frame_stride + nx_si));
                 nx_si++;
                 // renderKernel :286-291 + generateCameraRay :245-265:
                 //   (2*(x + xi)/W - 1) * half_w  ==  (x + xi) * (2*half_w/W) - half_w

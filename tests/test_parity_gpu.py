@@ -585,7 +585,9 @@ def test_frames_in_flight_launch_boundaries(gpu):
              [("camera", cam_b)] +
              [("render", 43 + k, 1, dict(fused_rgba8=1)) for k in range(6)] +      # another camera, with display
              [("camera", cam)] +
-             [("render", 49 + 2 * k, 2, dict(flags=abi.FLAG_NEE_MIS)) for k in range(3)])
+             [("render", 49 + 2 * k, 2, dict(flags=abi.FLAG_NEE_MIS)) for k in range(3)] +
+             [("render", 60 + 8 * k + 2, 2, dict()) for k in range(7)] +          # equally spaced: rank 1 of 4, 2 spp per step
+             [("render", 200, 1, dict()), ("render", 190, 1, dict())])            # going backwards: never one launch
     def run(r):
         _setup(r, sc, cam)
         for c in calls:
@@ -595,7 +597,7 @@ def test_frames_in_flight_launch_boundaries(gpu):
                 r.render(c[1], c[2], abi.render_params(**c[3]))
         return r.accum()
     want = run(gpu)
-    assert np.all(want[..., 3] == 5 + 12 + 6 + 3 + 6 + 6)
+    assert np.all(want[..., 3] == 5 + 12 + 6 + 3 + 6 + 6 + 14 + 2)
     for n in (2, 3, 8):
         gpu.set_frames_in_flight(n)
         try:
