@@ -117,6 +117,9 @@ def main() -> int:
         torch.cuda.synchronize()
 
     flags = abi.FLAG_NEE_MIS if args.mis else 0
+    # everything below -- the library's launches, the timing events, the reduce -- runs on one stream of torch's that
+    # is not the null stream (which synchronises with every other blocking stream of the process)
+    torch.cuda.set_stream(torch.cuda.Stream())
     r = Renderer(local_rank)
     r.use_torch_stream()
 
@@ -255,7 +258,8 @@ def main() -> int:
             pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
             if os.path.exists(pmc):
                 try:
-                    d["traffic"] = json.load(open(pmc)).get(leg["workload"], {}).get("hbm_bytes_per_launch")
+                    per_frame = json.load(open(pmc)).get(leg["workload"], {}).get("hbm_bytes_per_frame")   # PMC, path launch of many frames
+                    d["traffic"] = round(per_frame * fpl) if per_frame else None
                 except Exception:
                     pass
         if leg["serial_ms"]:

@@ -202,7 +202,7 @@ int join_chains(PtContext* ctx) {
     while (ctx->folds_queued < ctx->burst)
         if (int rc = queue_next_fold(ctx)) return rc;
     const uint32_t last = (ctx->burst - 1u) % ctx->flight;
-    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->fold_done[last], 0));
+    if (ctx->chain_stream[last] != ctx->stream) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->fold_done[last], 0));  // (chain 0 is the context's stream itself)
     ctx->burst = 0;
     ctx->folds_queued = 0;
     if (ctx->burst_displayed && !ctx->display_current) {
@@ -241,9 +241,12 @@ uint32_t frames_per_launch_max(const PtContext* ctx) {
 int prepare_chains(PtContext* ctx) {
     const size_t npix = (size_t)ctx->width * ctx->height;
     if (!ctx->fork_event) HIP_TRY(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
-    // chain 0 runs on the context's own stream: one stream fewer to share the process's hardware
-    // queues (GPU_MAX_HW_QUEUES, 4 by default; two chains on one queue serialise)
-    ctx->chain_stream[0] = ctx->own_stream;
+    // chain 0 runs on the context's current stream (its own, or the caller's: pt_set_stream joins the chains before it
+    // changes): one stream fewer to share the process's hardware queues (GPU_MAX_HW_QUEUES, 4 by default; two chains on
+    // one queue serialise), and a burst of a single launch -- 20 frames are one -- starts and ends without a hop
+    // between queues (two such hops cost 60 us of the 1.96 ms the driver's 20 frames took)
+    // (the null stream is not used as a chain: it synchronises with every blocking stream of the process)
+    ctx->chain_stream[0] = ctx->stream ? ctx->stream : ctx->own_stream;
     for (uint32_t c = 0; c < ctx->flight; ++c) {
         if (!ctx->chain_stream[c]) HIP_TRY(hipStreamCreateWithFlags(&ctx->chain_stream[c], hipStreamNonBlocking));
         if (!ctx->chain_done[c]) HIP_TRY(hipEventCreateWithFlags(&ctx->chain_done[c], hipEventDisableTiming));
@@ -375,7 +378,7 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
         chain = ctx->burst % ctx->flight;
         stream = ctx->chain_stream[chain];
         // (a chain's launches and fold passes alternate on its stream: its buffer is folded before it is written again)
-        if (ctx->burst < ctx->flight) PROF(ctx, 0, hipStreamWaitEvent(stream, ctx->fork_event, 0));  // first launch of this chain in the burst
+        if (ctx->burst < ctx->flight && stream != ctx->stream) PROF(ctx, 0, hipStreamWaitEvent(stream, ctx->fork_event, 0));  // first launch of this chain in the burst
         while (ctx->burst >= ctx->flight && ctx->folds_queued + ctx->flight <= ctx->burst)
             if (int rc = queue_next_fold(ctx)) return rc;
     }

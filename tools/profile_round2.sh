@@ -23,4 +23,10 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_wait -- $P > $O/pmc_wait.log 2>&1 || { echo "pmc wait failed"; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $P > $O/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $P > $O/pmc_write.log 2>&1 || { echo "pmc write failed"; exit 1; }
+# 4. the same four passes on the driver's command: its 20 timed frames are ONE launch of the path kernel (frames in flight collect
+#    them) followed by one fold pass; rocprofv3 serialises dispatches while it counts, which changes nothing for a single launch
+P2="python3 $B $DRV --cpu-seconds 0 --no-4k-leg"
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $O/pmcf_valu -- $P2 > $O/pmcf_valu.log 2>&1 || { echo "pmc valu (frames) failed"; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmcf_fetch -- $P2 > $O/pmcf_fetch.log 2>&1 || { echo "pmc fetch (frames) failed"; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmcf_write -- $P2 > $O/pmcf_write.log 2>&1 || { echo "pmc write (frames) failed"; exit 1; }
 echo "profile_round2 done"
