@@ -252,7 +252,7 @@ def main() -> int:
         d = {"bound": "valu", "kernel": "pt_path_kernel", "achieved": round(achieved, 4), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
              "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": None, "flops_per_launch": flops_per_launch,
              "flops_per_sample": round(leg["flops_per_frame"] / leg["samples_per_step"], 1),
-             "launches": leg["launches"], "frames_per_launch": round(fpl, 3),
+             "launches": leg["launches"], "steps_per_launch": round(fpl, 3),
              "kernel_ms": round(launch_ms, 5), "frame_ms": round(leg["frame_ms"], 5), "launch_overlap": leg["frames_in_flight"]}
         if with_traffic:
             pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")

@@ -448,6 +448,9 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
         const uint32_t by_fill = ((resident < six ? resident : six) * 27u) / (20u * ctx->flight);
         const uint32_t want = by_work > by_fill ? (by_work > resident ? resident : (uint32_t)by_work) : by_fill;
         if (want < cap) cap = want;
+        // (a launch of many frames: a quarter more waves than are resident -- the surplus starts as slots come free and
+        //  finds tickets left: 20 frames at 720p +1.5 %, 1024 frames +0.4 %; 150 % the same, 75 % -4 %)
+        if (frames > 1u && cap == resident) cap = resident + resident / 4u;
     }
     // work unit = 4x4 pixels; a ticket is at least units_per_grab of them.  Default: aim at >= 8
     // tickets per wave of the grid, but never more than one 8x8 tile per ticket -- two for launches of one

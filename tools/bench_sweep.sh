@@ -10,7 +10,9 @@ d=json.loads(open('gpurun_out/sweep_tmp.json').read().strip().splitlines()[-1])
 print('$label', 'steps', d['steps'], 'value', d['value'], 'ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
   done
 }
-run chain0_user "" X=1
-run chain0_own "" PT_AMD_CHAIN0_OWN=1
-run chain0_user "" X=1
-run chain0_own "" PT_AMD_CHAIN0_OWN=1
+run base "" X=1
+run grid75 "" PT_AMD_GRID_PCT=75
+run grid125 "" PT_AMD_GRID_PCT=125
+run grid150 "" PT_AMD_GRID_PCT=150
+run idle4 "" PT_AMD_IDLE_MIN=4
+run regen16 "" PT_AMD_REGEN_MIN=16

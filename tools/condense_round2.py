@@ -59,7 +59,8 @@ def nth_dispatch(sub, kernel_filter, n):
     for r in rows:
         if int(r["Dispatch_Id"]) == pick: agg[r["Counter_Name"]] += float(r["Counter_Value"])
     return dict(agg)
-frames = line(os.path.join(src, "bench_driver_args.json"))["roofline"]["frames_per_launch"]
+_r = line(os.path.join(src, "bench_driver_args.json"))["roofline"]
+frames = _r.get("steps_per_launch", _r.get("frames_per_launch"))
 multi = "pt_path_kernel<false, false, false>"   # the build overlapped launches use; dispatches: set-up, warm-up, the timed launch
 mf = {"source": f"tools/profile_round2.sh {tag}: rocprofv3 --pmc, one pass per counter group, bench.py --gpus 1 --steps 20 --warmup 5 --no-4k-leg: "
                 "the third dispatch of the path kernel is the launch that holds the 20 timed frames, the third fold pass the one behind it",

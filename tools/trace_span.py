@@ -29,10 +29,10 @@ first, last = min(st[i] for i in timed), max(en[i] for i in timed)
 folds_in = [r for r in fold if first <= int(r["Start_Timestamp"]) and int(r["Start_Timestamp"]) <= last + 200000]
 last_fold = max([int(r["End_Timestamp"]) for r in folds_in] + [last])
 busy = sum(en[i] - st[i] for i in timed)
-res = {"source": note, "timed_frames": K, "timed_launches": L, "frames_per_launch": K / L, "warmup": W, "frames_in_flight": F,
+res = {"source": note, "timed_steps": K, "timed_launches": L, "steps_per_launch": K / L, "warmup": W, "frames_in_flight": F,
        "first_start_to_last_end_ns": last - first, "ns_per_launch_amortised": (last - first) / L,
        "first_start_to_last_fold_end_ns": last_fold - first, "ns_per_launch_incl_last_fold": (last_fold - first) / L,
-       "ns_per_frame_incl_last_fold": (last_fold - first) / K,
+       "ns_per_step_incl_last_fold": (last_fold - first) / K,
        "mean_dispatch_duration_ns": busy / L, "mean_launches_in_flight": busy / (last - first),
        "fold_passes_in_span": len(folds_in), "mean_fold_duration_ns": (sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in folds_in) / max(len(folds_in), 1))}
 ser = range(len(path) - n_serial, len(path))
