@@ -5,15 +5,18 @@
 // (cuda_pathtracer/src/raytracer_kernel.cu:202-305 with Material.cuh:36-259); how it computes
 // it is not the reference's one-thread-one-pixel-one-sample launch:
 //
-//  * persistent lanes with path regeneration: a wave owns a pool of 8x8 pixel tiles; every
-//    lane traces ONE ray per loop iteration and, the moment its path ends, starts its next
-//    sample / pulls its next pixel from the pool with a wave-level ballot+mbcnt prefix (no
-//    LDS, no atomics).  Bounce-count divergence (mirror corridors run to depth 50 with no
-//    Russian roulette) therefore costs idle lanes only in a wave's last few
-//    iterations, not on every path.
-//  * a pixel is owned by exactly one lane per launch: its samples are summed in registers in
-//    sample order and added to the float4 accumulation buffer with one 16-byte load and one
-//    16-byte store — deterministic, no float atomics.
+//  * persistent lanes with path regeneration: a wave owns a pool of 4x4 pixel units drawn from
+//    a global ticket counter; every lane traces ONE ray per loop iteration and, the moment its
+//    path ends, continues with the camera ray it holds prepared (its pixel's next sample, or a
+//    pixel pulled from the pool with a wave-level ballot+mbcnt prefix: no LDS, no atomics).
+//    Bounce-count divergence (mirror corridors run to depth 50 with no Russian roulette,
+//    SURVEY D12) therefore costs idle lanes only in a wave's last few iterations.
+//  * a launch may hold several FRAMES (frames in flight, pt_api.cpp): the work items are
+//    (frame, pixel) pairs from one ticket space, each frame's sums go to a plane of their own.
+//  * a (frame, pixel) is owned by exactly one lane: its samples are summed in registers in
+//    sample order and stored with one 16-byte store (serial launches: added to the float4
+//    accumulation buffer with one 16-byte load and one 16-byte store) — deterministic, no
+//    float atomics.
 //  * the scene is read through wave-uniform indices, i.e. scalar loads into SGPRs (the scalar
 //    data cache is CDNA's constant memory); only the winning primitive is gathered per lane.
 //  * virtual dispatch is replaced by a material tag switch; curand by a counter RNG keyed on
@@ -63,10 +66,6 @@ hipError_t pt_scratch_setup(int device, uint32_t** out) {
     *out = g_scratch_ptr[device];
     return hipSuccess;
 }
-
-// (The number of lanes that must have ended their path before the regeneration steps are entered is a
-// launch argument, PathArgs::regen_min: 12 for one-sample launches, where every path end costs a flush, a
-// pull and a camera ray, +2 %; 1 otherwise, where larger values lose 1-3 %.)
 
 namespace {
 
