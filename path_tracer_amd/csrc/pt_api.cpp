@@ -296,10 +296,9 @@ inline uint32_t hash32(uint32_t x) {  // counter-RNG finaliser, DESIGN.md §RNG
 }
 
 
-// Frames in flight are for sums only (a running mean is a recurrence on one buffer), and not while a
-// per-launch trace is being written.
-bool can_overlap(const PtContext* ctx, const PtRenderParams* prm) {
-    return prm->acc_mode == PT_ACC_SUM && ctx->knob_trace.empty();
+// Frames in flight are for sums only (a running mean is a recurrence on one buffer).
+bool can_overlap(const PtContext* /*ctx*/, const PtRenderParams* prm) {
+    return prm->acc_mode == PT_ACC_SUM;
 }
 
 // Samples per frame when a call for several samples is cut into frames of a multi-frame launch (0: never cut).

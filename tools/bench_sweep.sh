@@ -11,8 +11,8 @@ print('$label', 'steps', d['steps'], 'value', d['value'], 'ms', d['ms_per_step']
   done
 }
 run base "" X=1
-run grid75 "" PT_AMD_GRID_PCT=75
-run grid125 "" PT_AMD_GRID_PCT=125
-run grid150 "" PT_AMD_GRID_PCT=150
-run idle4 "" PT_AMD_IDLE_MIN=4
-run regen16 "" PT_AMD_REGEN_MIN=16
+run pre240 "" PT_AMD_PREFETCH=240
+run pre224 "" PT_AMD_PREFETCH=224
+run pre192 "" PT_AMD_PREFETCH=192
+run pre128 "" PT_AMD_PREFETCH=128
+run base "" X=1

@@ -9,10 +9,11 @@ import numpy as np
 from path_tracer_amd import abi, scenes
 from path_tracer_amd.renderer import Renderer
 r = Renderer(0)
-for name, (w, h), spp in (("cuda_default", (1280, 720), 1), ("cuda_default", (1280, 720), 16), ("cuda_default", (3840, 2160), 16)):
+for name, (w, h), spp, frames in (("cuda_default", (1280, 720), 1, 1), ("cuda_default", (1280, 720), 1, 20), ("cuda_default", (3840, 2160), 16, 1)):
     sc, cam = scenes.builtin(name, w, h)
-    r.set_scene(sc); r.set_camera(cam); r.reset()
-    for i in range(3): r.render(i * spp, spp, abi.render_params(fused_rgba8=1))
+    r.set_frames_in_flight(1); r.set_scene(sc); r.set_camera(cam); r.reset()
+    r.set_frames_in_flight(3 if frames > 1 else 1)      # frames > 1: one launch of that many frames (the last launch is traced)
+    for i in range(3 if frames == 1 else frames): r.render(i * spp, spp, abi.render_params(fused_rgba8=1))
     r.sync()
     t = np.fromfile("/tmp/pt_trace.bin", dtype=np.uint64).reshape(-1, 16)
     t = t[t[:, 0] > 0]
@@ -21,7 +22,7 @@ for name, (w, h), spp in (("cuda_default", (1280, 720), 1), ("cuda_default", (12
     start, exh, few, end = us(t[:, 0]), us(t[:, 1]), us(t[:, 2]), us(t[:, 3])
     trips, ftrips, frays, ltrips = (t[:, k].astype(np.float64) for k in (4, 5, 6, 7))
     q = lambda x: np.percentile(x, [0, 10, 50, 90, 99, 100]).round(1).tolist()
-    print(f"== {name} {w}x{h} {spp} spp: {len(t)} waves, launch span {end.max():.1f} us")
+    print(f"== {name} {w}x{h} {spp} spp x {frames} frame(s): {len(t)} waves, launch span {end.max():.1f} us")
     print("   start            pct[0,10,50,90,99,100]", q(start))
     print("   frame exhausted  ", q(exh[t[:, 1] > 0]))
     print("   first few-trip   ", q(few[t[:, 2] > 0]))
