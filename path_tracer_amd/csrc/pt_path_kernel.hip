@@ -307,6 +307,12 @@ struct FewLds {
 
 __device__ __forceinline__ f4v to_f4v(float4 a) { f4v r; r.x = a.x; r.y = a.y; r.z = a.z; r.w = a.w; return r; }
 
+
+// element `index` of a scene array through a 32-bit byte offset from the uniform base (global_load ... v_off, s[base]):
+// the 64-bit per-lane address of `p[index]` costs the lane-parallel loops a register
+__device__ __forceinline__ float4 at32(const float4* p, uint32_t index) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p) + (size_t)(index * 16u));
+}
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit_few(const DevSceneF& sc, const FewLds& lds, uint64_t rays, int lane, V3 o, V3 d,
                                                 float& t_out, int& id_out, uint32_t& n_roots) {
@@ -320,16 +326,16 @@ __device__ __forceinline__ void closest_hit_few(const DevSceneF& sc, const FewLd
         // the first 64 of each kind from LDS (re-read per ray: keeping them in registers across the
         // main loop costs a wave of occupancy), the rest from global memory
         if (lane < sc.ns) sphere_test<COUNT>(to_f4v(lds.sph[lane]), lane, O, D, tb, ib, n_roots);
-        for (int i = 64 + lane; i - lane < sc.ns; i += 64)
-            if (i < sc.ns) sphere_test<COUNT>(to_f4v(sc.sph[i]), i, O, D, tb, ib, n_roots);
+        for (uint32_t i = 64u + (uint32_t)lane; i - (uint32_t)lane < (uint32_t)sc.ns; i += 64u)
+            if (i < (uint32_t)sc.ns) sphere_test<COUNT>(to_f4v(at32(sc.sph, i)), (int)i, O, D, tb, ib, n_roots);
         if (lane < sc.np) plane_test(to_f4v(lds.pla[lane]), sc.ns + lane, O, D, tb, ib);
-        for (int i = 64 + lane; i - lane < sc.np; i += 64)
-            if (i < sc.np) plane_test(to_f4v(sc.pla[i]), sc.ns + i, O, D, tb, ib);
+        for (uint32_t i = 64u + (uint32_t)lane; i - (uint32_t)lane < (uint32_t)sc.np; i += 64u)
+            if (i < (uint32_t)sc.np) plane_test(to_f4v(at32(sc.pla, i)), sc.ns + (int)i, O, D, tb, ib);
         if (lane < sc.nt)
             tri_test(to_f4v(lds.tri[3 * lane]), to_f4v(lds.tri[3 * lane + 1]), to_f4v(lds.tri[3 * lane + 2]), sc.ns + sc.np + lane, O, D, tb, ib);
-        for (int i = 64 + lane; i - lane < sc.nt; i += 64)
-            if (i < sc.nt)
-                tri_test(to_f4v(sc.tri[3 * i]), to_f4v(sc.tri[3 * i + 1]), to_f4v(sc.tri[3 * i + 2]), sc.ns + sc.np + i, O, D, tb, ib);
+        for (uint32_t i = 64u + (uint32_t)lane; i - (uint32_t)lane < (uint32_t)sc.nt; i += 64u)
+            if (i < (uint32_t)sc.nt)
+                tri_test(to_f4v(at32(sc.tri, 3u * i)), to_f4v(at32(sc.tri, 3u * i + 1u)), to_f4v(at32(sc.tri, 3u * i + 2u)), sc.ns + sc.np + (int)i, O, D, tb, ib);
         const float tl = t_of_key(tb);
         const float tmin = wave_min(tl);  // never NaN: every test stores only values that passed `<`
         const int winner = __builtin_ctzll(__ballot(tl == tmin));

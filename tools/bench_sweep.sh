@@ -11,8 +11,7 @@ print('$label', 'steps', d['steps'], 'value', d['value'], 'ms', d['ms_per_step']
   done
 }
 run base "" X=1
-run pre240 "" PT_AMD_PREFETCH=240
-run pre224 "" PT_AMD_PREFETCH=224
-run pre192 "" PT_AMD_PREFETCH=192
-run pre128 "" PT_AMD_PREFETCH=128
+run few3 "" PT_AMD_FEW_MAX=3
+run few2 "" PT_AMD_FEW_MAX=2
+run few6 "" PT_AMD_FEW_MAX=6
 run base "" X=1
