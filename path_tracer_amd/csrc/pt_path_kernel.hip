@@ -410,8 +410,8 @@ __device__ __forceinline__ const PT_CONST KArgs* cold() {
 #ifndef PT_NEE_WAVES
 #define PT_NEE_WAVES 6
 #endif
-// (the plain build with the lane-parallel mode needs 73 VGPRs, one over the step to 7 waves/SIMD; asked for 7 it
-//  fits 72 by spilling 31 SGPRs and runs 9 % slower than at 6 waves/SIMD: left alone)
+// (the plain build with the lane-parallel mode needs 71 VGPRs, 7 waves/SIMD, since its loops use 32-bit offsets; at
+//  73 it was asked for 7 waves, fitted 72 by spilling 31 SGPRs and ran 9 % slower: left alone)
 #ifndef PT_FEW_WAVES
 #define PT_FEW_WAVES 1
 #endif
@@ -430,8 +430,8 @@ __device__ __forceinline__ const PT_CONST KArgs* cold() {
 #define PT_OCC __attribute__((amdgpu_waves_per_eu(PT_WAVES_PER_EU)))
 #endif
 
-// FEW: the build with the lane-parallel closest hit.  Its mere presence costs the common loop 11 VGPRs and
-// 2-3 % (Cornell box, several samples per launch, overlapped launches), and it pays where waves drain alone
+// FEW: the build with the lane-parallel closest hit.  Its mere presence costs the common loop 8 VGPRs and
+// 3-4 % (Cornell box, several samples per launch, overlapped launches), and it pays where waves drain alone
 // (serial launches) or where the scene is large, so the host picks the build per launch (pt_api.cpp).
 template <bool NEE, bool COUNT, bool FEW>
 __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs kargs) {

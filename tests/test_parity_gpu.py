@@ -578,6 +578,8 @@ def test_frames_in_flight_launch_boundaries(gpu):
     camera.  Whatever the partition, the buffer is the serial loop's bit for bit."""
     sc, cam = scenes.cuda_default(160, 90)
     _, cam_b = scenes.glass_stress(160, 90)
+    cam_dof = abi.make_camera((0.0, 0.5, 3.5), (0.0, 0.0, 0.0), (0, 1, 0), 60.0, 160, 90, abi.CAMERA_CUDA, aspect_ratio=160 / 90,
+                              aperture=0.2, focus_dist=3.0, use_dof=1)
     calls = ([("render", s, 1, dict()) for s in range(5)] +                      # five frames of 1 spp
              [("render", 5 + 3 * k, 3, dict()) for k in range(4)] +               # four of 3 spp
              [("render", 17, 3, dict(max_depth=7)), ("render", 20, 3, dict(max_depth=7))] +  # other parameters
@@ -587,7 +589,9 @@ def test_frames_in_flight_launch_boundaries(gpu):
              [("camera", cam)] +
              [("render", 49 + 2 * k, 2, dict(flags=abi.FLAG_NEE_MIS)) for k in range(3)] +
              [("render", 60 + 8 * k + 2, 2, dict()) for k in range(7)] +          # equally spaced: rank 1 of 4, 2 spp per step
-             [("render", 200, 1, dict()), ("render", 190, 1, dict())])            # going backwards: never one launch
+             [("render", 200, 1, dict()), ("render", 190, 1, dict())] +           # going backwards: never one launch
+             [("camera", cam_dof)] +
+             [("render", 300 + k, 1, dict(fused_rgba8=1)) for k in range(5)])      # thin-lens rays (finished when the ray is taken)
     def run(r):
         _setup(r, sc, cam)
         for c in calls:
@@ -597,7 +601,7 @@ def test_frames_in_flight_launch_boundaries(gpu):
                 r.render(c[1], c[2], abi.render_params(**c[3]))
         return r.accum()
     want = run(gpu)
-    assert np.all(want[..., 3] == 5 + 12 + 6 + 3 + 6 + 6 + 14 + 2)
+    assert np.all(want[..., 3] == 5 + 12 + 6 + 3 + 6 + 6 + 14 + 2 + 5)
     for n in (2, 3, 8):
         gpu.set_frames_in_flight(n)
         try:
