@@ -366,6 +366,11 @@ int pt_valu_peak(PtContext* ctx, uint32_t packed, uint32_t iters, double* out_tf
  * ignored: the launch shape is the library's.  pt_host.hpp gives C++ hosts a
  * `dim3` with the (x = 1, y = 1, z = 1) constructor, so the reference's call site
  * (main.cu:208-212,287-288) compiles as it stands.
+ * Stream: the reference's loop works on the legacy default stream throughout
+ * (renderKernel, then convertToRGBAKernel on the same buffer).  A context whose
+ * stream nobody chose (pt_set_stream / pt_use_own_stream) moves to the null stream
+ * on its first call through this function, so the caller's own kernels and copies
+ * on `output` stay ordered with the launch as they were.
  * The function returns void like the reference's; its error channel is
  * pt_last_error(), which is empty after a launch that was enqueued (every entry
  * point clears the thread's message on entry), so

@@ -91,6 +91,7 @@ struct PtContext {
     // frames in flight (pt_set_frames_in_flight): launch k of a burst goes to chain k % flight, which
     // has its own stream and its own accumulator; chain 0's accumulator is the context's (or the bound one)
     uint32_t flight = 1;
+    bool stream_chosen = false;  // pt_set_stream / pt_use_own_stream was called (launchRenderKernel otherwise moves to the null stream)
     hipStream_t chain_stream[PT_MAX_CHAINS] = {};
     hipEvent_t chain_done[PT_MAX_CHAINS] = {};
     hipEvent_t fork_event = nullptr;
@@ -664,11 +665,13 @@ int pt_destroy(PtContext* ctx) {
 
 int pt_set_stream(PtContext* ctx, void* hip_stream) {
     if (int rc = use(ctx)) return rc;
+    ctx->stream_chosen = true;
     return switch_stream(ctx, (hipStream_t)hip_stream);
 }
 
 int pt_use_own_stream(PtContext* ctx) {
     if (int rc = use(ctx)) return rc;
+    ctx->stream_chosen = true;
     return switch_stream(ctx, ctx->own_stream);
 }
 
@@ -1208,6 +1211,14 @@ void launchRenderKernel(void* output, uint32_t width, uint32_t height, uint32_t 
     if (!ctx) { fail(PT_ERR_STATE, "launchRenderKernel: no current context (pt_make_current)"); return; }
     if (!output) { fail(PT_ERR_INVALID, "launchRenderKernel: output is null"); return; }
     if (width != ctx->width || height != ctx->height) { fail(PT_ERR_INVALID, "launchRenderKernel: %ux%u does not match the camera's %ux%u", width, height, ctx->width, ctx->height); return; }
+    // The reference's loop works on the legacy default stream throughout: renderKernel<<<grid, block>>> and then
+    // convertToRGBAKernel on the same `output` (raytracer_kernel.cu:326, Window.cuh:155-160).  A context whose stream
+    // nobody chose therefore moves to the null stream on its first call through this shim, so that the caller's own
+    // kernels and copies on `output` stay ordered with the launch as they were (the context's own stream is
+    // non-blocking: nothing would order them).  pt_set_stream / pt_use_own_stream keep their say.
+    if (!ctx->stream_chosen && ctx->stream == ctx->own_stream) {
+        if (hipSetDevice(ctx->device) != hipSuccess || switch_stream(ctx, nullptr) != PT_OK) return;
+    }
     float4* saved = ctx->accum;
     const bool saved_bound = ctx->accum_bound;
     if (pt_bind_accum(ctx, output) != PT_OK) return;

@@ -370,6 +370,33 @@ def test_launch_render_kernel_shim(gpu):
     assert np.all(shim[..., 3] == 1.0)
 
 
+def test_launch_render_kernel_shim_is_ordered_with_the_null_stream():
+    """The reference's frame loop runs everything on the legacy default stream: the launch, then its own
+    convertToRGBAKernel on the same buffer (main.cu:287-291, Window.cuh:155-160).  A context whose stream nobody chose
+    works on the null stream once it is driven through the shim, so a kernel the caller puts on the null stream
+    right behind the launch -- here torch's copy, no synchronisation in between -- sees the finished frame, and the
+    next launch waits for it."""
+    import torch
+    from path_tracer_amd.renderer import Renderer
+    sc, cam = scenes.cuda_default(1280, 720)      # a launch long enough (0.2 ms) for a missing order to show
+    r = Renderer(0)
+    try:
+        _setup(r, sc, cam)
+        out = torch.zeros((720, 1280, 4), device="cuda", dtype=torch.float32)
+        torch.cuda.synchronize()
+        snaps = []
+        for frame in range(4):
+            r.launch_render_kernel(out.data_ptr(), frame)
+            snaps.append(out.clone())               # on the null stream, like the reference's convertToRGBAKernel
+        torch.cuda.synchronize()
+        _setup(r, sc, cam)
+        for frame in range(4):
+            r.render(frame, 1, abi.render_params(acc_mode=abi.ACC_RUNNING_MEAN))
+            assert np.array_equal(snaps[frame].cpu().numpy(), r.accum()), frame
+    finally:
+        r.close()
+
+
 def test_resolve_bit_exact_on_same_buffer(gpu, oracle):
     sc, cam = scenes.cuda_default(160, 90)
     _setup(gpu, sc, cam)
