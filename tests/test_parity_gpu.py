@@ -1396,6 +1396,28 @@ def test_full_size_4k_properties(gpu):
     # both are 36-sample estimates of (nearly) the same pixel footprint: the difference is Monte-Carlo noise
     coarse = lambda m: np.clip(m, 0, 1).reshape(45, 16, 80, 16, 3).mean(axis=(1, 3))
     _bound("full_size_4k/coarse_mae_vs_720p", np.abs(coarse(m4k) - coarse(m720)).mean(), 0.03)   # measured 0.0117
+    # frames in flight at this size: a launch holds 16 frames (2^27 pixel-frames), its ticket space a million units --
+    # the largest dividends of the kernel's float-quotient divisions -- and 19 frames are two launches.  The image and
+    # the event counters are the serial loop's, bit for bit.
+    q = abi.render_params(max_depth=6, fused_rgba8=1, flags=abi.FLAG_COUNTERS)
+    _setup(gpu, sc, cam)
+    gpu.reset_counters()
+    for f in range(19):
+        gpu.render(f, 1, q)
+    serial, serial_rgba, serial_counters = gpu.accum(), gpu.readback(abi.RESOLVE_RGBA8_CUDA), gpu.counters().as_dict()
+    gpu.set_frames_in_flight(3)
+    try:
+        _setup(gpu, sc, cam)
+        gpu.reset_counters()
+        before = gpu.path_launches()
+        for f in range(19):
+            gpu.render(f, 1, q)
+        assert np.array_equal(gpu.accum(), serial)
+        assert gpu.path_launches() - before == 2
+        assert np.array_equal(gpu.readback(abi.RESOLVE_RGBA8_CUDA), serial_rgba)
+        assert gpu.counters().as_dict() == serial_counters
+    finally:
+        gpu.set_frames_in_flight(1)
     small = scenes.cuda_default(64, 36)
     gpu.set_scene(small[0])
     gpu.set_camera(small[1])
