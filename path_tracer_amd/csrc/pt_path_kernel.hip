@@ -37,6 +37,9 @@
 #ifndef PT_ONB
 #define PT_ONB 1
 #endif
+#ifndef PT_PEEL
+#define PT_PEEL 1
+#endif
 
 // ---- scratch of the entry point that allocates nothing (pt_render_noalloc, include/pt.h) ------------------
 // The path kernel's only memory beyond its inputs and outputs is its ticket counters.  pt_render takes them from a
@@ -234,7 +237,7 @@ __device__ __forceinline__ void tri_test(const f4v r0, const f4v r1, const f4v r
 // Closest hit over spheres, planes, triangles in that order with a strict '<'
 // (intersectScene, raytracer_kernel.cu:152-184).  Only (t, primitive id) are tracked; the hit
 // record is built once for the winner.
-template <bool COUNT>
+template <bool COUNT, bool PEEL>
 __device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, float& t_out, int& ibest,
                                             uint32_t& n_roots) {
     uint32_t tbest = TB_INIT;  // biased, see closer()
@@ -243,6 +246,24 @@ __device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, flo
     const float qnan = __builtin_nanf("");
     const V3 inv_d = v3(fabsf(d.x) >= 1e-6f ? rcp(d.x) : qnan, fabsf(d.y) >= 1e-6f ? rcp(d.y) : qnan,
                         fabsf(d.z) >= 1e-6f ? rcp(d.z) : qnan);
+    if (PEEL) {
+    // whole batches of four without guards (three scalar instructions per sphere, and the scalar pipe is the kernel's
+    // second bound), then the remainder behind wave-uniform scalar branches: a padding entry costs no vector work
+    int i = 0;
+    for (; i + 4 <= sc.ns; i += 4) {
+        const f4v s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
+        sphere_test<COUNT>(s0, i, o, d, tbest, ibest, n_roots);
+        sphere_test<COUNT>(s1, i + 1, o, d, tbest, ibest, n_roots);
+        sphere_test<COUNT>(s2, i + 2, o, d, tbest, ibest, n_roots);
+        sphere_test<COUNT>(s3, i + 3, o, d, tbest, ibest, n_roots);
+    }
+    if (i < sc.ns) {
+        const f4v s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2];
+        sphere_test<COUNT>(s0, i, o, d, tbest, ibest, n_roots);
+        if (i + 1 < sc.ns) sphere_test<COUNT>(s1, i + 1, o, d, tbest, ibest, n_roots);
+        if (i + 2 < sc.ns) sphere_test<COUNT>(s2, i + 2, o, d, tbest, ibest, n_roots);
+    }
+    } else {
     for (int i = 0; i < sc.ns; i += 4) {
         const f4v s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
         // the guards are wave-uniform scalar branches: a padding entry costs no vector work
@@ -250,6 +271,7 @@ __device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, flo
         if (i + 1 < sc.ns) sphere_test<COUNT>(s1, i + 1, o, d, tbest, ibest, n_roots);
         if (i + 2 < sc.ns) sphere_test<COUNT>(s2, i + 2, o, d, tbest, ibest, n_roots);
         if (i + 3 < sc.ns) sphere_test<COUNT>(s3, i + 3, o, d, tbest, ibest, n_roots);
+    }
     }
     axis_planes(as_const(sc.axp), sc.nax, o.x, inv_d.x, tbest, ibest);
     axis_planes(as_const(sc.axp) + sc.ax_off_y, sc.nay, o.y, inv_d.y, tbest, ibest);
@@ -262,11 +284,25 @@ __device__ __forceinline__ void closest_hit(const DevSceneF& sc, V3 o, V3 d, flo
         if (i + 2 < sc.npg) plane_test(p2, as_id(q2.x), o, d, tbest, ibest);
         if (i + 3 < sc.npg) plane_test(p3, as_id(q3.x), o, d, tbest, ibest);
     }
+    if (PEEL) {
+    int k = 0;
+    for (; k + 2 <= sc.nt; k += 2) {
+        const f4v a0 = tri[3 * k], a1 = tri[3 * k + 1], a2 = tri[3 * k + 2];
+        const f4v b0 = tri[3 * k + 3], b1 = tri[3 * k + 4], b2 = tri[3 * k + 5];
+        tri_test(a0, a1, a2, sc.ns + sc.np + k, o, d, tbest, ibest);
+        tri_test(b0, b1, b2, sc.ns + sc.np + k + 1, o, d, tbest, ibest);
+    }
+    if (k < sc.nt) {
+        const f4v a0 = tri[3 * k], a1 = tri[3 * k + 1], a2 = tri[3 * k + 2];
+        tri_test(a0, a1, a2, sc.ns + sc.np + k, o, d, tbest, ibest);
+    }
+    } else {
     for (int i = 0; i < sc.nt; i += 2) {
         const f4v a0 = tri[3 * i], a1 = tri[3 * i + 1], a2 = tri[3 * i + 2];
         const f4v b0 = tri[3 * i + 3], b1 = tri[3 * i + 4], b2 = tri[3 * i + 5];
         tri_test(a0, a1, a2, sc.ns + sc.np + i, o, d, tbest, ibest);
         if (i + 1 < sc.nt) tri_test(b0, b1, b2, sc.ns + sc.np + i + 1, o, d, tbest, ibest);
+    }
     }
     t_out = t_of_key(tbest);
 }
@@ -512,7 +548,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
         if (FEW && (uint32_t)__popcll(alive_mask) <= a.few_max) {  // wave-uniform: all lanes take part
             closest_hit_few<COUNT>(sc, few_lds, alive_mask, (int)lane, o, d, t_hit, id_hit, c_roots);
         } else if (alive) {
-            closest_hit<COUNT>(sc, o, d, t_hit, id_hit, c_roots);
+            closest_hit<COUNT, PT_PEEL != 0 && !NEE>(sc, o, d, t_hit, id_hit, c_roots);  // (light-sampling builds: the peeled loops cost 9 more spilled SGPRs, -1.5 %)
         }
         PT_SECTION(_isect)
         {
