@@ -271,7 +271,10 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
  * pt_set_camera, pt_resize); a caller that reads pt_accum_device_ptr() or a bound
  * buffer itself, or that waits on its own stream, calls pt_flush() first, which is
  * asynchronous on the context's stream.  A caller that flushes after every frame
- * gets serial launches.
+ * gets serial launches.  A frame that is held back has only been validated: a
+ * failure of its launch (an allocation of the chains' buffers, say) is reported by
+ * the call that launches it -- a later pt_render, pt_flush or any of the calls
+ * above -- and pt_destroy drops frames that were never launched.
  * n > 3 needs more hardware queues than HIP's default of 4 per process:
  * GPU_MAX_HW_QUEUES >= n + 4 in the environment before HIP initialises (16 for
  * n = 8).  Chains that share a queue serialise (with the default, 4 chains are
