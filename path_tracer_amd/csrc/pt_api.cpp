@@ -209,6 +209,7 @@ int join_chains(PtContext* ctx) {
     if (ctx->burst_displayed && !ctx->display_current) {
         // some launch of the burst asked for a display and a later one did not: redo it from the sums
         HIP_TRY(pt_launch_resolve(ctx->accum, ctx->display, ctx->width * ctx->height, PT_ACC_SUM, PT_RESOLVE_RGBA8_CUDA, ctx->stream));
+        ctx->history_frames = 0;  // (the display no longer continues the history planes)
     }
     ctx->burst_displayed = false;
     return PT_OK;

@@ -968,7 +968,7 @@ __global__ __launch_bounds__(256) void pt_fold_kernel(float4* __restrict__ accum
     float4 a = accum[p];
     const float4* q = planes + p;
     // display of frame f: the last one into the display buffer, the others into history plane f (newest == nullptr: none)
-    uint32_t* h = newest ? history + p : nullptr;
+    uint32_t* h = (newest && history) ? history + p : nullptr;  // (no history planes when a launch holds one frame)
     uint32_t f = 0;
     for (; f + 4u < frames; f += 4u) {  // four loads in flight; the last frame is always left to the tail below
         const float4 q0 = q[0], q1 = q[plane_stride], q2 = q[2u * (size_t)plane_stride], q3 = q[3u * (size_t)plane_stride];
