@@ -5,7 +5,7 @@ GPU): the Cornell box of cuda_pathtracer/src/main.cu at 1280x720, progressive re
 1 sample per pixel per frame with the display (RGBA8) made for every frame.
 A "step" is one frame: one pt_render call over all 921 600 pixels, the call the reference's frame loop makes
 (launchRenderKernel, main.cu:287).  With frames in flight (the default here) the library collects consecutive frames
-into one launch of the path kernel (up to 32; include/pt.h) and folds them into the accumulation buffer one by one,
+into one launch of the path kernel (up to 64; include/pt.h) and folds them into the accumulation buffer one by one,
 making every frame's RGBA8 display on the way: same sums and same pictures as one launch per frame, bit for bit.
   N = 1 : K frames on one GPU.
   N > 1 : sample-split, weak scaling — every rank renders K frames of 1 spp for its own
@@ -63,7 +63,7 @@ def main() -> int:
     ap.add_argument("--mis", action="store_true", help="next-event estimation + MIS (north_star variant)")
     ap.add_argument("--pixels-per-wave", type=int, default=0)
     ap.add_argument("--frames-in-flight", type=int, default=3, choices=tuple(range(1, 9)),
-                    help="launches overlapped on internal streams, each holding up to 32 consecutive frames (include/pt.h); "
+                    help="launches overlapped on internal streams, each holding up to 64 consecutive frames (include/pt.h); "
                          "1 = one serial launch per frame.  3 is what HIP's default of 4 hardware queues per process allows")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg; 0 disables it")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),

@@ -247,11 +247,11 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
  *  - Consecutive calls with the same parameters and sample count whose sample
  *    ranges are equally spaced -- each starting where the one before it ended (the
  *    reference's loop is exactly that), or a fixed distance further on (a rank of a
- *    sample-split render takes its slice of every step) -- are collected -- up to 32 of them, fewer on frames beyond 4 Mpixel
- *    (2^27 pixel-frames per launch), one on frames wider or taller than 8192 -- and
+ *    sample-split render takes its slice of every step) -- are collected -- up to 64 of them, fewer on frames beyond 2 Mpixel
+ *    (2^27 pixel-frames per launch) -- and
  *    leave as ONE launch of the path kernel when that many have gathered or when
  *    anything needs their result.  The launch hands out (frame, pixel) pairs from one
- *    ticket space: one ramp and one tail instead of one per frame, and 32 x as many
+ *    ticket space: one ramp and one tail instead of one per frame, and 64 x as many
  *    work items per lane as a frame has (2.3 pixels per resident lane at 1280x720).
  *  - Launches go round-robin to n internal streams, so launch k+1 fills the
  *    compute units that launch k leaves idle while its last long paths finish.
@@ -283,7 +283,7 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
  * or <= 7, GPU_MAX_HW_QUEUES - 4 beyond that.  The call still returns PT_OK;
  * pt_frames_in_flight() returns the number in effect.  Memory: per chain one
  * plane of the frame's size (16 B per pixel) for every frame a launch may hold
- * (472 MB at 1280x720, at most 2 GiB), plus 4 B per pixel and frame for the
+ * (944 MB at 1280x720, at most 2 GiB), plus 4 B per pixel and frame for the
  * display history (one per context).
  *
  * Large calls.  Within a frame a pixel's samples belong to one lane, so one launch
@@ -316,7 +316,7 @@ int pt_resolve(PtContext* ctx, uint32_t mode);
 int pt_readback(PtContext* ctx, void* host_dst, size_t bytes);
 /* Frames in flight: the displays (RGBA8, as pt_readback returns them) that the last
  * fold pass made BEFORE its newest one, which is in the display buffer.
- * pt_history_frames() returns how many are held (0 .. 31; 0 after anything else
+ * pt_history_frames() returns how many are held (0 .. 63; 0 after anything else
  * wrote the display: pt_resolve, a serial launch with fused_rgba8, pt_reset);
  * frames_back = 1 is the frame before the newest.  Both first launch and fold
  * what is in flight.  No counterpart in the reference, whose loop shows each

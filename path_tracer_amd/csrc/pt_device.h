@@ -70,7 +70,8 @@ struct PathArgs {
     // of every pixel (frame_stride = count for one process; count * ranks when the samples of a step are split among
     // GPUs) and writes its sums to accum + f * plane_stride.  The work items are (frame, pixel) pairs from one
     // ticket space, frame-major.  A lane keeps (x, y, frame) of its next ray packed in one register: x in bits
-    // [0, xw), y in [xw, xw + yw), frame in [jo, jo + jw); 16 / 16 / - for one frame, 13 / 13 / 6 for several.
+    // [0, xw), y in [xw, xw + yw), frame in [jo, jo + jw); 16 / 16 / - for one frame; for several, as many bits as width and
+    // height need and the rest for the frame.
     uint32_t frames, plane_stride, frame_stride;
     uint32_t xw, yw, jo, jw;
     uint64_t* trace;            // per-wave timeline, 16 x u64 per wave (PT_TRACE kernel builds only; else nullptr)

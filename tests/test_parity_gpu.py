@@ -550,14 +550,14 @@ def test_frames_in_flight_match_serial(gpu, n):
 
 
 def test_frames_in_flight_make_every_frames_display(gpu):
-    """Frames in flight collect consecutive frames into one launch (up to 32) and fold them one by one: the display
+    """Frames in flight collect consecutive frames into one launch (up to 64) and fold them one by one: the display
     of EVERY frame is made, from the sums as they stand after that frame -- the newest in the display buffer, the
     ones before it in the history planes -- and each equals, byte for byte, the display the serial loop shows after
     that frame (renderKernel + convertToRGBAKernel per frame, main.cu:284-303)."""
     from path_tracer_amd._lib import PtError
     sc, cam = scenes.cuda_default(192, 108)
     p = abi.render_params(fused_rgba8=1)
-    frames = 41   # one launch of 32 frames and one of 9
+    frames = 70   # one launch of 64 frames and one of 6
     _setup(gpu, sc, cam)
     serial = []
     for s in range(frames):
@@ -578,20 +578,22 @@ def test_frames_in_flight_make_every_frames_display(gpu):
             gpu.readback_history(11)
         with pytest.raises(PtError, match="not held"):
             gpu.readback_history(0)
-        for s in range(11, frames):                      # 30 more: the burst continues on the same buffer
+        for s in range(11, frames):                      # 59 more: the burst continues on the same buffer
             gpu.render(s, 1, p)
         assert np.array_equal(gpu.accum(), serial_acc)
         assert np.array_equal(gpu.readback(abi.RESOLVE_RGBA8_CUDA), serial[frames - 1])
-        assert gpu.history_frames() == 29
-        for back in (1, 2, 15, 29):
+        assert gpu.history_frames() == 58
+        for back in (1, 2, 15, 31, 58):
             assert np.array_equal(gpu.readback_history(back), serial[frames - 1 - back]), back
-        # more frames than one launch holds, in one go: 32 + 9; the history is the last fold pass's
+        # more frames than one launch holds, in one go: 64 + 6; the history is the last fold pass's
         _setup(gpu, sc, cam)
+        before = gpu.path_launches()
         for s in range(frames):
             gpu.render(s, 1, p)
         assert np.array_equal(gpu.accum(), serial_acc)
-        assert gpu.history_frames() == 8
-        for back in range(1, 9):
+        assert gpu.path_launches() - before == 2
+        assert gpu.history_frames() == 5
+        for back in range(1, 6):
             assert np.array_equal(gpu.readback_history(back), serial[frames - 1 - back]), back
         gpu.resolve(abi.RESOLVE_RGBA8_CUDA)              # anything else that writes the display ends the history
         assert gpu.history_frames() == 0
@@ -638,22 +640,27 @@ def test_frames_in_flight_launch_boundaries(gpu):
         assert np.array_equal(got, want), n
 
 
-def test_frames_in_flight_on_a_frame_wider_than_the_packed_coordinates(gpu):
-    """A lane keeps (x, y, frame) of its next ray in one register, 13 bits per coordinate when a launch holds several
-    frames; a frame wider or taller than 8192 gets one frame per launch (16 bits per coordinate) and still overlaps."""
-    sc, cam = scenes.cuda_default(8200, 8)
+@pytest.mark.parametrize("size", [(8200, 8), (8, 8200), (65536, 2)])
+def test_frames_in_flight_on_long_thin_frames(gpu, size):
+    """A lane keeps (x, y, frame) of its next ray in one register; the bits are dealt out by the frame's shape (14 + 3
+    for 8200 x 8, 17 + 1 for 65536 x 2, the rest for the frame number), so frames far from 16:9 are collected into
+    launches like any other and give the serial loop's image and displays."""
+    sc, cam = scenes.cuda_default(*size)
+    q = abi.render_params(max_depth=6, fused_rgba8=1)
     _setup(gpu, sc, cam)
     for s in range(5):
-        gpu.render(s, 1, abi.render_params(max_depth=6, fused_rgba8=1))
+        gpu.render(s, 1, q)
     want, want_rgba = gpu.accum(), gpu.readback(abi.RESOLVE_RGBA8_CUDA)
     gpu.set_frames_in_flight(2)
     try:
         _setup(gpu, sc, cam)
+        before = gpu.path_launches()
         for s in range(5):
-            gpu.render(s, 1, abi.render_params(max_depth=6, fused_rgba8=1))
+            gpu.render(s, 1, q)
         assert np.array_equal(gpu.accum(), want)
+        assert gpu.path_launches() - before == 1
         assert np.array_equal(gpu.readback(abi.RESOLVE_RGBA8_CUDA), want_rgba)
-        assert gpu.history_frames() == 0
+        assert gpu.history_frames() == 4
     finally:
         gpu.set_frames_in_flight(1)
     _setup(gpu, *scenes.cuda_default(64, 36))   # (back to a small frame: the chains' buffers are resized with it)

@@ -10,8 +10,8 @@ d=json.loads(open('gpurun_out/sweep_tmp.json').read().strip().splitlines()[-1])
 print('$label', 'steps', d['steps'], 'value', d['value'], 'ms', d['ms_per_step'], 'frac', d['roofline']['frac'])"
   done
 }
-run base "" X=1
-run few3 "" PT_AMD_FEW_MAX=3
-run few2 "" PT_AMD_FEW_MAX=2
-run few6 "" PT_AMD_FEW_MAX=6
-run base "" X=1
+run base64 "" X=1
+run cap128 "" PT_AMD_FRAMES_CAP=128
+run cap96 "" PT_AMD_FRAMES_CAP=96
+run cap32 "" PT_AMD_FRAMES_CAP=32
+run base64 "" X=1
