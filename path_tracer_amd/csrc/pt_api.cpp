@@ -91,21 +91,29 @@ struct PtContext {
     // frames in flight (pt_set_frames_in_flight): launch k of a burst goes to chain k % flight, which
     // has its own stream and its own accumulator; chain 0's accumulator is the context's (or the bound one)
     uint32_t flight = 1;
+    bool own_burst = false;      // the chains are in use for a call that the library cut into frames by itself (render_in_parts on a default context)
     bool stream_chosen = false;  // pt_set_stream / pt_use_own_stream was called (launchRenderKernel otherwise moves to the null stream)
+    // launchRenderKernel renders into the caller's `output`; with frames in flight the binding stays across consecutive
+    // calls on the same buffer (so that they can be collected into one launch) and is undone by the next other entry point
+    bool shim_active = false;
+    float4* shim_saved = nullptr;
+    bool shim_saved_bound = false;
     hipStream_t chain_stream[PT_MAX_CHAINS] = {};
     hipEvent_t chain_done[PT_MAX_CHAINS] = {};
     hipEvent_t fork_event = nullptr;
     float4* chain_acc[PT_MAX_CHAINS] = {};  // per chain: the sums of the chain's launch in flight (written whole by it, folded
                                             // into the accumulation buffer by the pass behind it)
-    size_t chain_acc_pixels = 0;
+    size_t chain_cap[PT_MAX_CHAINS] = {};   // per chain: planes (frames) its buffer holds; grown on demand up to frames_per_launch_max()
     hipEvent_t fold_done[PT_MAX_CHAINS] = {};  // per chain: the fold pass behind its last launch (and, through the chain of
                                                // waits, every earlier fold pass of the burst) is done
     bool display_current = false;           // the display buffer holds the mean of everything folded so far
     uint32_t folds_queued = 0;              // fold passes of the open burst enqueued so far (launches 0 .. folds_queued-1)
     bool fold_rgba[PT_MAX_CHAINS] = {};     // per chain: the launch whose fold pass is not enqueued yet asked for a display
     uint32_t chain_frames[PT_MAX_CHAINS] = {};  // per chain: frames of the launch whose fold pass is not enqueued yet
-    size_t chain_planes = 0;           // planes (frames) each chain buffer holds
+    uint32_t chain_s0[PT_MAX_CHAINS] = {}, chain_stride[PT_MAX_CHAINS] = {}, chain_mode[PT_MAX_CHAINS] = {};  // ... its first frame's sample
+                                       // index, the distance between its frames, its PT_ACC_* mode (the running mean's weights)
     uint32_t* history = nullptr;       // displays of the frames before the newest of the last fold pass, one plane each
+    size_t history_cap = 0;            // planes `history` holds; grown on demand
     uint32_t history_frames = 0;       // planes of `history` that hold a picture (frame history_frames-1 is the newest but one)
     // Frames collected for the next overlapped launch (pt_render calls that were accepted but not launched yet)
     struct Pending { uint32_t begin = 0, per_frame = 0, stride = 0, frames = 0; PtRenderParams prm{}; } pending;
@@ -121,6 +129,7 @@ struct PtContext {
     uint32_t resident_blocks[8] = {};  // per kernel build (nee, count, few)
     // tuning / tracing knobs for tools/gpu_ab.py and tools/gpu_trace.py, read once at pt_create
     // (PT_AMD_FEW_MAX, PT_AMD_MAX_BLOCKS, PT_AMD_GRID_PCT, PT_AMD_FRAMES, PT_AMD_CHUNK, PT_AMD_REGEN_MIN, PT_AMD_IDLE_MIN, PT_AMD_PREFETCH, PT_AMD_TRACE); -1 / empty = not set
+    bool knob_fail_chain_alloc = false;   // PT_AMD_FAIL_CHAIN_ALLOC=1 (tests): the chains' buffers cannot be allocated
     int knob_few_max = -1, knob_max_blocks = -1, knob_chunk = -1, knob_regen_min = -1, knob_idle_min = -1, knob_prefetch = -1, knob_grid_pct = -1, knob_frames = -1;
     std::string knob_trace;
 };
@@ -129,16 +138,36 @@ namespace {
 
 // First statement of every entry point that takes a context: clears the thread's error message (so it is
 // empty after a call that succeeds) and makes the context's device current.
+int join_chains(PtContext* ctx);
+int queue_next_fold(PtContext* ctx);
+int launch_pending(PtContext* ctx, bool joining = false);
+
+// launchRenderKernel left the caller's `output` bound (frames in flight): fold what is held back into it and give the
+// context its own buffer back.
+int end_shim_binding(PtContext* ctx) {
+    if (!ctx->shim_active) return PT_OK;
+    const int rc = join_chains(ctx);
+    ctx->accum = ctx->shim_saved; ctx->accum_bound = ctx->shim_saved_bound;
+    ctx->shim_active = false;
+    return rc;
+}
+
 int use(PtContext* ctx) {
     pt_clear_error();
     if (!ctx) return fail(PT_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
-    return PT_OK;
+    return end_shim_binding(ctx);
 }
 
-int join_chains(PtContext* ctx);
-int queue_next_fold(PtContext* ctx);
-int launch_pending(PtContext* ctx, bool joining = false);
+void free_chain_buffers(PtContext* ctx) {  // (hipFree synchronises the device: nothing queued still uses them)
+    for (uint32_t c = 0; c < PT_MAX_CHAINS; ++c) {
+        if (ctx->chain_acc[c]) { (void)hipFree(ctx->chain_acc[c]); ctx->chain_acc[c] = nullptr; }
+        ctx->chain_cap[c] = 0;
+    }
+    if (ctx->history) { (void)hipFree(ctx->history); ctx->history = nullptr; }
+    ctx->history_cap = 0;
+    ctx->history_frames = 0;
+}
 
 int alloc_frame(PtContext* ctx, uint32_t w, uint32_t h) {
     if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) return fail(PT_ERR_INVALID, "bad frame size %ux%u", w, h);
@@ -161,6 +190,7 @@ int alloc_frame(PtContext* ctx, uint32_t w, uint32_t h) {
     if (ctx->accum_own) (void)hipFree(ctx->accum_own);
     if (ctx->display) (void)hipFree(ctx->display);
     if (ctx->ids) { (void)hipFree(ctx->ids); ctx->ids = nullptr; }
+    free_chain_buffers(ctx);  // sized for the old frame; the display history too (pt_history_frames() is 0 from here on)
     ctx->accum_own = accum_new;
     ctx->display = display_new;
     ctx->width = w;
@@ -186,7 +216,7 @@ int queue_next_fold(PtContext* ctx) {
     const uint32_t npix = ctx->width * ctx->height, frames = ctx->chain_frames[chain];
     if (k > 0) PROF(ctx, 2, hipStreamWaitEvent(stream, ctx->fold_done[(k - 1u) % ctx->flight], 0));
     PROF(ctx, 3, pt_launch_fold(ctx->accum, ctx->chain_acc[chain], npix, frames, ctx->fold_rgba[chain] ? (uint32_t*)ctx->display : nullptr,
-                                ctx->history, npix, stream));
+                                ctx->history, npix, ctx->chain_mode[chain], ctx->chain_s0[chain], ctx->chain_stride[chain], stream));
     PROF(ctx, 4, hipEventRecord(ctx->fold_done[chain], stream));
     ctx->display_current = ctx->fold_rgba[chain];
     if (ctx->fold_rgba[chain]) ctx->history_frames = frames - 1u;
@@ -208,7 +238,7 @@ int join_chains(PtContext* ctx) {
     ctx->folds_queued = 0;
     if (ctx->burst_displayed && !ctx->display_current) {
         // some launch of the burst asked for a display and a later one did not: redo it from the sums
-        HIP_TRY(pt_launch_resolve(ctx->accum, ctx->display, ctx->width * ctx->height, PT_ACC_SUM, PT_RESOLVE_RGBA8_CUDA, ctx->stream));
+        HIP_TRY(pt_launch_resolve(ctx->accum, ctx->display, ctx->width * ctx->height, ctx->last_acc_mode, PT_RESOLVE_RGBA8_CUDA, ctx->stream));
         ctx->history_frames = 0;  // (the display no longer continues the history planes)
     }
     ctx->burst_displayed = false;
@@ -245,9 +275,8 @@ uint32_t frames_per_launch_max(const PtContext* ctx) {
     return fit < 1u ? 1u : (uint32_t)fit;
 }
 
-// Streams, events and buffers of the chains for the current frame size.
+// Streams and events of the chains.
 int prepare_chains(PtContext* ctx) {
-    const size_t npix = (size_t)ctx->width * ctx->height;
     if (!ctx->fork_event) HIP_TRY(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
     // chain 0 runs on the context's current stream (its own, or the caller's: pt_set_stream joins the chains before it
     // changes): one stream fewer to share the process's hardware queues (GPU_MAX_HW_QUEUES, 4 by default; two chains on
@@ -260,18 +289,40 @@ int prepare_chains(PtContext* ctx) {
         if (!ctx->chain_done[c]) HIP_TRY(hipEventCreateWithFlags(&ctx->chain_done[c], hipEventDisableTiming));
         if (!ctx->fold_done[c]) HIP_TRY(hipEventCreateWithFlags(&ctx->fold_done[c], hipEventDisableTiming));
     }
-    const size_t planes = frames_per_launch_max(ctx);
-    if (ctx->chain_acc_pixels != npix || ctx->chain_planes != planes) {
-        for (uint32_t c = 0; c < PT_MAX_CHAINS; ++c)
-            if (ctx->chain_acc[c]) { HIP_TRY(hipFree(ctx->chain_acc[c])); ctx->chain_acc[c] = nullptr; }
-        if (ctx->history) { HIP_TRY(hipFree(ctx->history)); ctx->history = nullptr; }
-        ctx->chain_acc_pixels = npix;
-        ctx->chain_planes = planes;
-        ctx->history_frames = 0;
+    return PT_OK;
+}
+
+// The buffers one overlapped launch needs: `frames` planes of sums on its chain and, when it displays, frames - 1
+// planes of display history.  Allocated on the chain's first launch, never for chains that are not used.  Size: a
+// caller that asked for frames in flight (pt_set_frames_in_flight) has opted into their memory and gets the most a
+// launch may hold at once, so that no launch of the frame loop ever reallocates (a 295-MB hipFree + hipMalloc inside
+// the driver's 20 timed frames cost 0.8 ms of 2); a call that the library cuts into frames on its own (a default
+// context, render_in_parts) takes what that call holds -- 16 planes for 16 samples, not 64 on every chain -- and
+// grows on demand.  Buffers only grow, so a fold pass that is enqueued later finds the history at least as large as
+// it needs.  The chain's previous fold pass is already enqueued when this runs (launch_now), and hipFree
+// synchronises the device, so nothing still uses what is replaced.
+// Returns PT_NO_MEMORY (> 0, internal) when the device has no room: the caller then renders the frames serially.
+constexpr int PT_NO_MEMORY = 1;
+int ensure_chain_buffers(PtContext* ctx, uint32_t chain, uint32_t frames, bool displayed) {
+    const size_t npix = (size_t)ctx->width * ctx->height;
+    if (ctx->knob_fail_chain_alloc) return PT_NO_MEMORY;
+    const uint32_t most = frames_per_launch_max(ctx);
+    if (ctx->chain_cap[chain] < frames) {
+        if (ctx->chain_acc[chain]) { HIP_TRY(hipFree(ctx->chain_acc[chain])); ctx->chain_acc[chain] = nullptr; ctx->chain_cap[chain] = 0; }
+        uint32_t planes = (ctx->own_burst || most < frames) ? frames : most;
+        hipError_t e = hipMalloc((void**)&ctx->chain_acc[chain], (size_t)planes * npix * sizeof(float4));
+        if (e != hipSuccess && planes > frames) { (void)hipGetLastError(); planes = frames; e = hipMalloc((void**)&ctx->chain_acc[chain], (size_t)planes * npix * sizeof(float4)); }
+        if (e != hipSuccess) { (void)hipGetLastError(); ctx->chain_acc[chain] = nullptr; return PT_NO_MEMORY; }
+        ctx->chain_cap[chain] = planes;   // written whole by every launch: no clear
     }
-    for (uint32_t c = 0; c < ctx->flight; ++c)
-        if (!ctx->chain_acc[c]) HIP_TRY(hipMalloc((void**)&ctx->chain_acc[c], planes * npix * sizeof(float4)));  // written whole by every launch
-    if (!ctx->history && planes > 1) HIP_TRY(hipMalloc((void**)&ctx->history, (planes - 1) * npix * sizeof(uint32_t)));
+    if (displayed && frames > 1u && ctx->history_cap < frames - 1u) {
+        if (ctx->history) { HIP_TRY(hipFree(ctx->history)); ctx->history = nullptr; ctx->history_cap = 0; ctx->history_frames = 0; }
+        uint32_t planes = (ctx->own_burst || most < frames) ? frames - 1u : most - 1u;
+        hipError_t e = hipMalloc((void**)&ctx->history, (size_t)planes * npix * sizeof(uint32_t));
+        if (e != hipSuccess && planes > frames - 1u) { (void)hipGetLastError(); planes = frames - 1u; e = hipMalloc((void**)&ctx->history, (size_t)planes * npix * sizeof(uint32_t)); }
+        if (e != hipSuccess) { (void)hipGetLastError(); ctx->history = nullptr; return PT_NO_MEMORY; }
+        ctx->history_cap = planes;
+    }
     return PT_OK;
 }
 
@@ -304,9 +355,11 @@ inline uint32_t hash32(uint32_t x) {  // counter-RNG finaliser, DESIGN.md §RNG
 }
 
 
-// Frames in flight are for sums only (a running mean is a recurrence on one buffer).
-bool can_overlap(const PtContext* /*ctx*/, const PtRenderParams* prm) {
-    return prm->acc_mode == PT_ACC_SUM;
+// Frames in flight hold sums and the reference's running mean alike: a launch writes every frame's own value into a
+// plane, and the fold pass applies the recurrence -- acc += frame, or acc = frame * t + acc * (1 - t) with
+// t = 1 / (frame_count + 1), raytracer_kernel.cu:297-304 -- frame after frame in launch order.
+bool can_overlap(const PtContext* /*ctx*/, const PtRenderParams* /*prm*/) {
+    return true;
 }
 
 // Samples per frame when a call for several samples is cut into frames of a multi-frame launch (0: never cut).
@@ -328,7 +381,7 @@ uint32_t part_size(const PtContext* ctx, uint32_t sample_count) {
 // depends on the call's arguments and the frame size only -- not on the frames in flight -- so the image is
 // the same bit for bit either way.
 bool wants_parts(const PtContext* ctx, uint32_t sample_count, const PtRenderParams* prm) {
-    if (!can_overlap(ctx, prm) || (uint64_t)ctx->width * ctx->height > (1ull << 22)) return false;
+    if (prm->acc_mode != PT_ACC_SUM || (uint64_t)ctx->width * ctx->height > (1ull << 22)) return false;
     const uint32_t part = part_size(ctx, sample_count);
     return part > 0 && sample_count > part && sample_count >= 4u;
 }
@@ -347,6 +400,7 @@ int render_in_parts(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count
     PtRenderParams sub = *prm;
     if (!pipelined) {
         ctx->flight = ctx->burst_chains;
+        ctx->own_burst = true;
         sub.fused_rgba8 = 0;
     }
     uint32_t begin = sample_begin, left = sample_count;
@@ -359,6 +413,7 @@ int render_in_parts(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count
     if (!pipelined) {
         const int rj = join_chains(ctx);
         ctx->flight = user_flight;
+        ctx->own_burst = false;
         if (rc == PT_OK) rc = rj;
         if (rc == PT_OK && prm->fused_rgba8) rc = pt_resolve(ctx, PT_RESOLVE_RGBA8_CUDA);
     }
@@ -388,6 +443,7 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
         if (ctx->burst < ctx->flight && stream != ctx->stream) PROF(ctx, 0, hipStreamWaitEvent(stream, ctx->fork_event, 0));  // first launch of this chain in the burst
         while (ctx->burst >= ctx->flight && ctx->folds_queued + ctx->flight <= ctx->burst)
             if (int rc = queue_next_fold(ctx)) return rc;
+        if (int rc = ensure_chain_buffers(ctx, chain, frames, prm->fused_rgba8 != 0)) return rc;  // (PT_NO_MEMORY: launch_pending renders serially)
     }
     PathArgs a{};
     // A launch that overlaps others writes its own sums (sum_r, sum_g, sum_b, count) whole into its chain's buffer;
@@ -399,9 +455,9 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     a.counters = (prm->flags & PT_FLAG_COUNTERS) ? ctx->counters : nullptr;
     a.s0 = sample_begin; a.count = sample_count;
     a.frames = frames; a.plane_stride = ctx->width * ctx->height; a.frame_stride = frame_stride;
-    if (frames > 1u) {   // (x, y, frame) of a lane's next ray in one register: as many bits as each needs
-        a.xw = bits_for(ctx->width); a.yw = bits_for(ctx->height); a.jo = a.xw + a.yw; a.jw = 32u - a.jo;
-    } else { a.xw = 16u; a.yw = 16u; a.jo = 0u; a.jw = 0u; }
+    // (x, y, frame) of a lane's next ray in one register: as many bits as each needs (a frame is at most 2^28 pixels, so
+    // x and y fit in 30 bits however long and thin it is); no bits for the frame number of a one-frame launch
+    a.xw = bits_for(ctx->width); a.yw = bits_for(ctx->height); a.jo = a.xw + a.yw; a.jw = frames > 1u ? 32u - a.jo : 0u;
     a.max_depth = prm->max_depth; a.rr_depth = prm->rr_depth; a.seed_hash = hash32(prm->seed);
     a.light_colour = (prm->flags & PT_FLAG_LIGHT_COLOUR) ? 1u : 0u;
     a.acc_mode = prm->acc_mode;
@@ -521,6 +577,7 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     ctx->path_launches++;
     if (pipelined) {
         ctx->chain_frames[chain] = frames;
+        ctx->chain_s0[chain] = sample_begin; ctx->chain_stride[chain] = frame_stride; ctx->chain_mode[chain] = prm->acc_mode;
         ctx->fold_rgba[chain] = prm->fused_rgba8 != 0;   // its fold pass is enqueued later (queue_next_fold)
         if (prm->fused_rgba8) ctx->burst_displayed = true;
         ctx->burst++;
@@ -545,7 +602,14 @@ int launch_pending(PtContext* ctx, bool joining) {
     // a single frame with nothing to overlap and nothing to follow (the caller flushes after every frame): the serial
     // launch does the same sums without a fold pass behind it
     if (joining && p.frames == 1u && ctx->burst == 0) return launch_now(ctx, p.begin, p.per_frame, 1u, p.per_frame, &p.prm, nullptr, false);
-    return launch_now(ctx, p.begin, p.per_frame, p.frames, p.frames > 1u ? p.stride : p.per_frame, &p.prm, nullptr, true);
+    const int rc = launch_now(ctx, p.begin, p.per_frame, p.frames, p.frames > 1u ? p.stride : p.per_frame, &p.prm, nullptr, true);
+    if (rc != PT_NO_MEMORY) return rc;
+    // no room for the planes of an overlapped launch: fold what is in flight, then one serial launch per frame, which
+    // needs no buffer beyond the accumulation buffer and gives the same sums and the same pictures
+    if (int rj = join_chains(ctx)) return rj;
+    for (uint32_t f = 0; f < p.frames; ++f)
+        if (int rs = launch_now(ctx, p.begin + f * (p.frames > 1u ? p.stride : 0u), p.per_frame, 1u, p.per_frame, &p.prm, nullptr, false)) return rs;
+    return PT_OK;
 }
 
 // One pt_render call (or one part of a large one).  With frames in flight the call is a FRAME of the next overlapped
@@ -616,6 +680,7 @@ int pt_create(int device_id, PtContext** out) {
     if (const char* e = getenv("PT_AMD_PREFETCH")) ctx->knob_prefetch = atoi(e);
     if (const char* e = getenv("PT_AMD_GRID_PCT")) ctx->knob_grid_pct = atoi(e);
     if (const char* e = getenv("PT_AMD_FRAMES")) ctx->knob_frames = atoi(e);
+    if (const char* e = getenv("PT_AMD_FAIL_CHAIN_ALLOC")) ctx->knob_fail_chain_alloc = atoi(e) != 0;
     if (const char* e = getenv("GPU_MAX_HW_QUEUES")) {  // HIP reads the same variable when it initialises
         const int q = atoi(e) - 4;
         ctx->burst_chains = q < 3 ? 3u : (q > (int)PT_MAX_CHAINS ? PT_MAX_CHAINS : (uint32_t)q);
@@ -942,8 +1007,7 @@ int pt_set_camera(PtContext* ctx, const PtCamera* c) {
     return PT_OK;
 }
 
-int pt_bind_accum(PtContext* ctx, void* dev_float4) {
-    if (int rc = use(ctx)) return rc;
+static int bind_accum(PtContext* ctx, void* dev_float4) {
     if (ctx->width == 0) return fail(PT_ERR_STATE, "set the frame size (pt_set_camera / pt_resize) before binding a buffer");
     if (int rc = join_chains(ctx)) return rc;  // samples in flight belong to the buffer bound so far
     if (dev_float4) {
@@ -955,6 +1019,11 @@ int pt_bind_accum(PtContext* ctx, void* dev_float4) {
     return PT_OK;
 }
 
+int pt_bind_accum(PtContext* ctx, void* dev_float4) {
+    if (int rc = use(ctx)) return rc;
+    return bind_accum(ctx, dev_float4);
+}
+
 int pt_reset(PtContext* ctx) {
     if (int rc = use(ctx)) return rc;
     if (!ctx->accum) return fail(PT_ERR_STATE, "no frame allocated");
@@ -964,8 +1033,7 @@ int pt_reset(PtContext* ctx) {
     return PT_OK;
 }
 
-int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm) {
-    if (int rc = use(ctx)) return rc;
+static int render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm) {
     if (!prm) return fail(PT_ERR_INVALID, "params is null");
     if (!ctx->have_scene) return fail(PT_ERR_STATE, "no scene uploaded");
     if (!ctx->have_camera) return fail(PT_ERR_STATE, "no camera set");
@@ -988,6 +1056,11 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
         return fail(PT_ERR_INVALID, "the running-mean mode adds one sample per launch, like renderKernel");
     if (wants_parts(ctx, sample_count, prm)) return render_in_parts(ctx, sample_begin, sample_count, prm);
     return launch_path(ctx, sample_begin, sample_count, prm);
+}
+
+int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm) {
+    if (int rc = use(ctx)) return rc;
+    return render(ctx, sample_begin, sample_count, prm);
 }
 
 int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32_t height, uint32_t sample_begin,
@@ -1042,8 +1115,7 @@ int pt_readback(PtContext* ctx, void* host_dst, size_t bytes) {
 }
 
 uint32_t pt_history_frames(PtContext* ctx) {
-    pt_clear_error();
-    if (!ctx || join_chains(ctx) != PT_OK) return 0u;
+    if (use(ctx) != PT_OK || join_chains(ctx) != PT_OK) return 0u;   // (a failure leaves its message in pt_last_error())
     return ctx->history_frames;
 }
 
@@ -1224,17 +1296,32 @@ void launchRenderKernel(void* output, uint32_t width, uint32_t height, uint32_t 
     // nobody chose therefore moves to the null stream on its first call through this shim, so that the caller's own
     // kernels and copies on `output` stay ordered with the launch as they were (the context's own stream is
     // non-blocking: nothing would order them).  pt_set_stream / pt_use_own_stream keep their say.
+    const hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) { fail(PT_ERR_HIP, "launchRenderKernel: hipSetDevice(%d) failed: %s", ctx->device, hipGetErrorString(e)); return; }
     if (!ctx->stream_chosen && ctx->stream == ctx->own_stream) {
-        if (hipSetDevice(ctx->device) != hipSuccess || switch_stream(ctx, nullptr) != PT_OK) return;
+        if (end_shim_binding(ctx) != PT_OK || switch_stream(ctx, nullptr) != PT_OK) return;
     }
-    float4* saved = ctx->accum;
-    const bool saved_bound = ctx->accum_bound;
-    if (pt_bind_accum(ctx, output) != PT_OK) return;
+    // The caller's `output` becomes the accumulation buffer for this call.  Without frames in flight the context's own
+    // buffer is bound again before the call returns.  With them the binding stays while consecutive calls name the same
+    // buffer, so that the frames can be collected into one launch (a caller that does not read `output` between its
+    // launches gets the multi-frame launch; pt_flush() before it reads); the next entry point other than this one
+    // folds what is held back into `output` and undoes the binding (use()).
+    if (!(ctx->shim_active && ctx->accum == (float4*)output)) {
+        if (end_shim_binding(ctx) != PT_OK) return;
+        float4* const saved = ctx->accum;
+        const bool saved_bound = ctx->accum_bound;
+        if (bind_accum(ctx, output) != PT_OK) return;
+        ctx->shim_active = true; ctx->shim_saved = saved; ctx->shim_saved_bound = saved_bound;
+    }
     PtRenderParams p{};
     p.integrator = PT_INTEGRATOR_PATH; p.max_depth = 50; p.rr_depth = 3; p.seed = 0x5EED0001u;  // :294, :233
     p.acc_mode = PT_ACC_RUNNING_MEAN;
-    (void)pt_render(ctx, frame_count, 1, &p);  // a failure leaves its message in pt_last_error()
-    ctx->accum = saved; ctx->accum_bound = saved_bound;
+    (void)render(ctx, frame_count, 1, &p);  // a failure leaves its message in pt_last_error()
+    if (ctx->flight <= 1u) {   // nothing is held back: the binding ends here (join_chains inside finds nothing to do)
+        std::string msg = g_err;
+        (void)end_shim_binding(ctx);
+        g_err = msg;
+    }
 }
 
 }  // extern "C"

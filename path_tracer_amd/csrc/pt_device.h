@@ -74,6 +74,8 @@ struct PathArgs {
     // height need and the rest for the frame.
     uint32_t frames, plane_stride, frame_stride;
     uint32_t xw, yw, jo, jw;
+    // dynamic LDS image of the lane-parallel builds (laid out by pt_launch_path, in float4 units): spheres at 0, planes, triangle rows
+    uint32_t lds_off_pla, lds_off_tri;
     uint64_t* trace;            // per-wave timeline, 16 x u64 per wave (PT_TRACE kernel builds only; else nullptr)
 };
 
@@ -107,6 +109,10 @@ constexpr uint32_t PT_SCRATCH_BYTES = 4096;
 // Resolves (once per device, with that device current) and returns the device address of this GPU's copy.
 hipError_t pt_scratch_setup(int device, uint32_t** out);
 
+// Most dynamic LDS a path-kernel workgroup (one wave) takes: 28 waves per CU x 5.5 KB stay within the CU's 160 KB, so
+// LDS never costs a wave of occupancy.  The occupancy query is made with this figure.
+constexpr uint32_t PT_LDS_MAX_BYTES = 5632;
+
 // ---- launchers implemented in the .hip translation units ------------------------------
 hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArgs& a, bool nee, bool count, bool few,
                           uint32_t blocks, hipStream_t stream);
@@ -118,8 +124,9 @@ hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint
 // plane_stride pixels apart) to the accumulation buffer, frame after frame; with newest != nullptr it makes every
 // frame's display on the way: the last frame's into `newest`, frame f < frames - 1 into history + f * npix
 constexpr uint32_t PT_MAX_CHAINS = 8;
+// acc_mode = PT_ACC_*: sums are added; the running mean takes frame f (the caller's frame_count s0 + f * stride) with weight 1 / (frame_count + 1)
 hipError_t pt_launch_fold(float4* accum, const float4* planes, uint32_t plane_stride, uint32_t frames, uint32_t* newest,
-                          uint32_t* history, uint32_t npix, hipStream_t stream);
+                          uint32_t* history, uint32_t npix, uint32_t acc_mode, uint32_t s0, uint32_t stride, hipStream_t stream);
 hipError_t pt_launch_valu_peak(float* sink, uint32_t packed, uint32_t iters, uint32_t blocks, hipStream_t stream);
 hipError_t pt_launch_primary_ids(const DevSceneD& sc, const DevCamD& cam, uint32_t* obj, uint32_t* mat,
                                  hipStream_t stream);

@@ -40,6 +40,19 @@
 #ifndef PT_PEEL
 #define PT_PEEL 1
 #endif
+// 1: the regeneration block is skipped outright in trips that have nothing to flush, prepare or take (a wave that
+//    drains its last long paths: no kernarg re-reads, no ballots): serial 720p / 1 spp frames +1 %
+#ifndef PT_SKIPREGEN
+#define PT_SKIPREGEN 1
+#endif
+// 1: the lane-parallel closest hit reads the lane's LDS rows together and tests without branches (130 -> 100
+//    instructions per ray, two LDS waits instead of five): +0.3 %
+#ifndef PT_FEWFAST
+#define PT_FEWFAST 1
+#endif
+// (round 3, measured and dropped: s_setprio 2 / 3 for waves that hold a path of depth >= 6 / 10 / 16 / 24, always or
+//  once the tickets are gone: -1 ... +0.6 %; no hashes for a smooth metal's unused draws in the lane-parallel builds:
+//  +0.2 %)
 
 // ---- scratch of the entry point that allocates nothing (pt_render_noalloc, include/pt.h) ------------------
 // The path kernel's only memory beyond its inputs and outputs is its ticket counters.  pt_render takes them from a
@@ -336,14 +349,16 @@ __device__ __forceinline__ float wave_min(float v) {
     return fminf(fminf(readlane_f(v, 0), readlane_f(v, 16)), fminf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 
-// The first 64 primitives of each kind are staged in LDS by the block (5 KB) at kernel start:
-// a ds_read costs ~100 cycles where a global load that hits L2 costs ~1000, and in this mode the
-// wave has no other work to hide it behind.  Primitives beyond 64 of a kind come from global memory.
+// The first 64 primitives of each kind are staged in LDS by the block at kernel start (as many as the scene has:
+// 432 B for the Cornell box, at most 5 KB): a ds_read costs ~100 cycles where a global load that hits L2 costs ~500,
+// and in this mode the wave has no other work to hide it behind.  Primitives beyond 64 of a kind come from global
+// memory.  The image is dynamic LDS, laid out by the host (PathArgs::lds_*): spheres | planes | triangle rows.
 struct FewLds {
-    float4 sph[64];
-    float4 pla[64];
-    float4 tri[3 * 64];
+    const float4* sph;
+    const float4* pla;
+    const float4* tri;
 };
+extern __shared__ float4 pt_lds[];
 
 __device__ __forceinline__ f4v to_f4v(float4 a) { f4v r; r.x = a.x; r.y = a.y; r.z = a.z; r.w = a.w; return r; }
 
@@ -353,9 +368,27 @@ __device__ __forceinline__ f4v to_f4v(float4 a) { f4v r; r.x = a.x; r.y = a.y; r
 __device__ __forceinline__ float4 at32(const float4* p, uint32_t index) {
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p) + (size_t)(index * 16u));
 }
-template <bool COUNT>
+// The running minimum of one lane in the lane-parallel mode: selects, not a branch (one ray, a handful of busy lanes: an
+// exec-masked region costs its three scalar instructions and a taken branch, with nothing to skip).
+__device__ __forceinline__ void closer_sel(bool also, float t, int id, uint32_t& tb, int& ib) {
+    const uint32_t k = t_key(t);
+    const bool take = also && k < tb;
+    tb = take ? k : tb;
+    ib = take ? id : ib;
+}
+template <bool COUNT, bool FAST>
 __device__ __forceinline__ void closest_hit_few(const DevSceneF& sc, const FewLds& lds, uint64_t rays, int lane, V3 o, V3 d,
                                                 float& t_out, int& id_out, uint32_t& n_roots) {
+    // FAST (the builds without light sampling; with it the build is at its register limit and spills):
+    // The lane's own primitive of each kind among the first 64: its five LDS rows are read together, one wait for all
+    // (clamped indices: a lane beyond the count reads a row that exists and its result is masked out).  Read per trip,
+    // not once per launch: held across the main loop they would cost a wave of occupancy.
+    const bool has_s = lane < sc.ns, has_p = lane < sc.np, has_t = lane < sc.nt;
+    const int is = min(lane, max(sc.ns, 1) - 1), ip = min(lane, max(sc.np, 1) - 1), it = min(lane, max(sc.nt, 1) - 1);
+    const f4v S = to_f4v(FAST && sc.ns > 0 ? lds.sph[is] : make_float4(0, 0, 0, -1.0f));
+    const f4v P = to_f4v(FAST && sc.np > 0 ? lds.pla[ip] : make_float4(0, 0, 0, 0));
+    f4v T2 = {0, 0, 0, 0};   // (the triangle's other two rows are read per ray, after the sphere and the plane are done with
+    if (FAST && sc.nt > 0) T2 = to_f4v(lds.tri[3 * it + 2]);   //  their registers: all five rows at once take the build past 80 VGPRs)
     while (rays != 0ull) {
         const int L = __builtin_ctzll(rays);
         rays &= rays - 1ull;
@@ -363,16 +396,47 @@ __device__ __forceinline__ void closest_hit_few(const DevSceneF& sc, const FewLd
         const V3 D = v3(readlane_f(d.x, L), readlane_f(d.y, L), readlane_f(d.z, L));
         uint32_t tb = TB_INIT;  // biased (closer()); valid keys order like the floats they stand for
         int ib = -1;
-        // the first 64 of each kind from LDS (re-read per ray: keeping them in registers across the
-        // main loop costs a wave of occupancy), the rest from global memory
-        if (lane < sc.ns) sphere_test<COUNT>(to_f4v(lds.sph[lane]), lane, O, D, tb, ib, n_roots);
+        if constexpr (FAST) {   // sphere_test without its branches
+            const V3 oc = v3(O.x - S.x, O.y - S.y, O.z - S.z);
+            const float half_b = dot(oc, D);
+            const float c = fmaf(oc.x, oc.x, fmaf(oc.y, oc.y, fmaf(oc.z, oc.z, -S.w)));
+            const float disc = half_b * half_b - c;
+            const bool real = has_s && disc >= 0.0f;
+            if (COUNT) n_roots += real ? 1u : 0u;
+            const float sq = fsqrt(fmaxf(disc, 0.0f));
+            const float r0 = -half_b - sq, r1 = sq - half_b;
+            closer_sel(real, r0 >= RAY_MIN_T ? r0 : r1, lane, tb, ib);
+        } else {
+            // the first 64 of each kind from LDS (re-read per ray: keeping them in registers across the
+            // main loop costs a wave of occupancy), the rest from global memory
+            if (lane < sc.ns) sphere_test<COUNT>(to_f4v(lds.sph[lane]), lane, O, D, tb, ib, n_roots);
+        }
         for (uint32_t i = 64u + (uint32_t)lane; i - (uint32_t)lane < (uint32_t)sc.ns; i += 64u)
             if (i < (uint32_t)sc.ns) sphere_test<COUNT>(to_f4v(at32(sc.sph, i)), (int)i, O, D, tb, ib, n_roots);
-        if (lane < sc.np) plane_test(to_f4v(lds.pla[lane]), sc.ns + lane, O, D, tb, ib);
+        if constexpr (FAST) {   // plane_test
+            const float denom = P.x * D.x + P.y * D.y + P.z * D.z;
+            const float q = fmaf(P.x, O.x, fmaf(P.y, O.y, fmaf(P.z, O.z, P.w)));
+            closer_sel(has_p && fabsf(denom) >= 1e-6f, q * rcp(-denom), sc.ns + lane, tb, ib);
+        } else {
+            if (lane < sc.np) plane_test(to_f4v(lds.pla[lane]), sc.ns + lane, O, D, tb, ib);
+        }
         for (uint32_t i = 64u + (uint32_t)lane; i - (uint32_t)lane < (uint32_t)sc.np; i += 64u)
             if (i < (uint32_t)sc.np) plane_test(to_f4v(at32(sc.pla, i)), sc.ns + (int)i, O, D, tb, ib);
-        if (lane < sc.nt)
-            tri_test(to_f4v(lds.tri[3 * lane]), to_f4v(lds.tri[3 * lane + 1]), to_f4v(lds.tri[3 * lane + 2]), sc.ns + sc.np + lane, O, D, tb, ib);
+        if constexpr (FAST) {
+          if (sc.nt > 0) {   // tri_test (wave-uniform guard: a scene without triangles skips it)
+            const float oz = fmaf(T2.x, O.x, fmaf(T2.y, O.y, fmaf(T2.z, O.z, T2.w)));
+            const float dz = T2.x * D.x + T2.y * D.y + T2.z * D.z;
+            const float t = oz * rcp(-dz);
+            const V3 h = v3(O.x + D.x * t, O.y + D.y * t, O.z + D.z * t);
+            const f4v T0 = to_f4v(lds.tri[3 * it]), T1 = to_f4v(lds.tri[3 * it + 1]);
+            const float u = fmaf(T0.x, h.x, fmaf(T0.y, h.y, fmaf(T0.z, h.z, T0.w)));
+            const float v = fmaf(T1.x, h.x, fmaf(T1.y, h.y, fmaf(T1.z, h.z, T1.w)));
+            closer_sel(has_t && u >= 0.0f && v >= 0.0f && u + v <= 1.0f, t, sc.ns + sc.np + lane, tb, ib);
+          }
+        } else {
+            if (lane < sc.nt)
+                tri_test(to_f4v(lds.tri[3 * lane]), to_f4v(lds.tri[3 * lane + 1]), to_f4v(lds.tri[3 * lane + 2]), sc.ns + sc.np + lane, O, D, tb, ib);
+        }
         for (uint32_t i = 64u + (uint32_t)lane; i - (uint32_t)lane < (uint32_t)sc.nt; i += 64u)
             if (i < (uint32_t)sc.nt)
                 tri_test(to_f4v(at32(sc.tri, 3u * i)), to_f4v(at32(sc.tri, 3u * i + 1u)), to_f4v(at32(sc.tri, 3u * i + 2u)), sc.ns + sc.np + (int)i, O, D, tb, ib);
@@ -404,6 +468,11 @@ __device__ __forceinline__ uint32_t pack_rgba8_cuda(float r, float g, float b) {
     const uint32_t B = (uint32_t)fminf(fmaxf(b * 255.0f, 0.0f), 255.0f);
     return (R << 16) | (G << 8) | B;
 }
+
+// One step of the reference's running mean, renderKernel :297-304: c * t + prev * (1 - t), t = 1 / (frame_count + 1).
+// One function for the path kernel's flush and the fold pass, with the contraction spelled out, so that the serial
+// launch and the multi-frame launch round alike.
+__device__ __forceinline__ float mean_step(float c, float prev, float t) { return __builtin_fmaf(c, t, prev * (1.0f - t)); }
 
 __device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -488,12 +557,14 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
     uint32_t unit0 = 0, pool_size = 0, pool_next = 0;  // wave-uniform; unit0 counts within the shard
     bool exhausted = false;                             // wave-uniform
     if (blockIdx.x == 0 && threadIdx.x < 8u) a.next_counter[threadIdx.x * 32u] = 0u;
-    __shared__ FewLds few_lds;
-    if (FEW && threadIdx.x < 64u) {
+    const FewLds few_lds = {pt_lds, pt_lds + a.lds_off_pla, pt_lds + a.lds_off_tri};
+    if (threadIdx.x < 64u) {
         const int i = (int)threadIdx.x;
-        if (i < sc.ns) few_lds.sph[i] = sc.sph[i];
-        if (i < sc.np) few_lds.pla[i] = sc.pla[i];
-        if (i < sc.nt) { few_lds.tri[3 * i] = sc.tri[3 * i]; few_lds.tri[3 * i + 1] = sc.tri[3 * i + 1]; few_lds.tri[3 * i + 2] = sc.tri[3 * i + 2]; }
+        if (FEW) {
+            if (i < sc.ns) pt_lds[i] = sc.sph[i];
+            if (i < sc.np) pt_lds[a.lds_off_pla + i] = sc.pla[i];
+            if (i < sc.nt) { float4* t = pt_lds + a.lds_off_tri + 3 * i; t[0] = sc.tri[3 * i]; t[1] = sc.tri[3 * i + 1]; t[2] = sc.tri[3 * i + 2]; }
+        }
     }
     __syncthreads();
 
@@ -550,7 +621,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
         if (tr_in_few) { if (!tr_few) tr_few = wall_clock64(); tr_few_trips++; tr_few_rays += (uint32_t)__popcll(alive_mask); }
 #endif
         if (FEW && (uint32_t)__popcll(alive_mask) <= a.few_max) {  // wave-uniform: all lanes take part
-            closest_hit_few<COUNT>(sc, few_lds, alive_mask, (int)lane, o, d, t_hit, id_hit, c_roots);
+            closest_hit_few<COUNT, PT_FEWFAST != 0 && !NEE>(sc, few_lds, alive_mask, (int)lane, o, d, t_hit, id_hit, c_roots);
         } else if (alive) {
             closest_hit<COUNT, PT_PEEL != 0 && !NEE>(sc, o, d, t_hit, id_hit, c_roots);  // (light-sampling builds: the peeled loops cost 9 more spilled SGPRs, -1.5 %)
         }
@@ -569,6 +640,8 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
             if (alive && id >= 0) {
                 // ---- (5) hit record of the winner (:66-71, :95-100, :142-147; Intersection.cuh:29-32):
                 //          three independent 16-B gathers from one 64-B line
+                // (round 3: the same three rows staged in LDS for scenes of <= 64 primitives -- within +-1 % in every
+                //  workload, serial launches included; the L1 serves 19 hot lines as well: dropped)
                 const float4 g0 = sc.rec[4 * id], g1 = sc.rec[4 * id + 1], g2 = sc.rec[4 * id + 2];
                 const V3 p = o + d * t;
                 V3 n = id < sc.ns ? (p - xyz(g0)) * g0.w : xyz(g0);
@@ -742,7 +815,13 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
         // no idle lane-trips.  Samples of a pixel are still traced one after the other by one lane, in order: the
         // sums are bit-identical to the single-buffered loop's.
         const uint64_t dead_mask = __ballot(!alive);
-        if (dead_mask != 0ull) {
+        // (builds with the lane-parallel mode -- serial launches, where waves drain long paths alone: the block is skipped
+        //  outright unless there is something to flush or to take (a dead lane that owns a pixel or holds a prepared ray)
+        //  or something to prepare (tickets remain, or some lane's pixel has samples left to generate); in launches of
+        //  many frames the test costs more than the few trips it shortens, -0.5 ... -1 %)
+        const bool regen_work = !(FEW && PT_SKIPREGEN != 0) || !exhausted ||
+                                __ballot((!alive && (cur_valid || nx_valid)) || (!nx_valid && nx_si < a.count)) != 0ull;
+        if (dead_mask != 0ull && regen_work) {
         const PT_CONST KArgs* kc = cold();
         // ---- (1) a pixel whose last sample just ended is flushed: one 16-B store (its 16-B load was issued when the
         //          pixel was taken, so the latency is long gone)
@@ -751,12 +830,12 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
             if (a.acc_mode == 0u) {  // PT_ACC_SUM (prev is zero in a launch that writes its own sums whole)
                 acc = make_float4(prev.x + sum.x, prev.y + sum.y, prev.z + sum.z, prev.w + (float)a.count);
             } else {  // PT_ACC_RUNNING_MEAN, renderKernel :297-304 (count == 1, s0 = frame_count)
-                acc = make_float4(sum.x, sum.y, sum.z, 1.0f);
-                if (a.s0 > 0u) {
+                acc = make_float4(sum.x, sum.y, sum.z, 1.0f);   // (a launch of several frames writes the frame's own value: the
+                if (a.s0 > 0u && a.overwrite == 0u) {           //  fold pass applies the recurrence, pt_fold_kernel)
                     const float t = kc->a.mean_t;
-                    acc.x = sum.x * t + prev.x * (1.0f - t);
-                    acc.y = sum.y * t + prev.y * (1.0f - t);
-                    acc.z = sum.z * t + prev.z * (1.0f - t);
+                    acc.x = mean_step(sum.x, prev.x, t);
+                    acc.y = mean_step(sum.y, prev.y, t);
+                    acc.z = mean_step(sum.z, prev.z, t);
                 }
             }
             a.accum[pixel] = acc;
@@ -953,33 +1032,50 @@ __global__ __launch_bounds__(256) void pt_resolve_kernel(const float4* __restric
 // the reference's frame loop (main.cu:284-303): the newest goes to the display buffer, the ones before it to the
 // history planes (pt_download_display_history).  HBM-bound: per pixel 16 B read per frame, 16 B read + 16 B written
 // per pass, 4 B written per displayed frame, beside path launches that are VALU-bound and leave HBM idle.
-__device__ __forceinline__ void fold_frame(float4& a, const float4 q, uint32_t* dst) {
-    a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
-    if (dst) {
-        const float inv = a.w > 0.0f ? 1.0f / a.w : 0.0f;
-        *dst = pack_rgba8_cuda(a.x * inv, a.y * inv, a.z * inv);
+// MEAN: the frames hold one sample each and the buffer the reference's running mean (PT_ACC_RUNNING_MEAN): frame f of
+// the launch is the caller's frame_count n = s0 + f * stride, which overwrites when n == 0 and otherwise enters with
+// weight t = 1 / (n + 1) -- the same float division the host makes for a serial launch (PathArgs::mean_t).
+template <bool MEAN>
+__device__ __forceinline__ void fold_frame(float4& a, const float4 q, uint32_t* dst, uint32_t n) {
+    if (MEAN) {
+        if (n == 0u) { a.x = q.x; a.y = q.y; a.z = q.z; }
+        else {
+            const float t = 1.0f / (float)(n + 1u);
+            a.x = mean_step(q.x, a.x, t); a.y = mean_step(q.y, a.y, t); a.z = mean_step(q.z, a.z, t);
+        }
+        a.w = 1.0f;
+        if (dst) *dst = pack_rgba8_cuda(a.x, a.y, a.z);
+    } else {
+        a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+        if (dst) {
+            const float inv = a.w > 0.0f ? 1.0f / a.w : 0.0f;
+            *dst = pack_rgba8_cuda(a.x * inv, a.y * inv, a.z * inv);
+        }
     }
 }
+template <bool MEAN>
 __global__ __launch_bounds__(256) void pt_fold_kernel(float4* __restrict__ accum, const float4* __restrict__ planes, uint32_t plane_stride,
                                                       uint32_t frames, uint32_t* __restrict__ newest, uint32_t* __restrict__ history,
-                                                      uint32_t npix) {
+                                                      uint32_t npix, uint32_t s0, uint32_t stride) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= npix) return;
     float4 a = accum[p];
     const float4* q = planes + p;
     // display of frame f: the last one into the display buffer, the others into history plane f (newest == nullptr: none)
     uint32_t* h = (newest && history) ? history + p : nullptr;  // (no history planes when a launch holds one frame)
-    uint32_t f = 0;
+    uint32_t f = 0, n = s0;
     for (; f + 4u < frames; f += 4u) {  // four loads in flight; the last frame is always left to the tail below
         const float4 q0 = q[0], q1 = q[plane_stride], q2 = q[2u * (size_t)plane_stride], q3 = q[3u * (size_t)plane_stride];
-        fold_frame(a, q0, h); fold_frame(a, q1, h ? h + npix : nullptr);
-        fold_frame(a, q2, h ? h + 2u * (size_t)npix : nullptr); fold_frame(a, q3, h ? h + 3u * (size_t)npix : nullptr);
+        fold_frame<MEAN>(a, q0, h, n); fold_frame<MEAN>(a, q1, h ? h + npix : nullptr, n + stride);
+        fold_frame<MEAN>(a, q2, h ? h + 2u * (size_t)npix : nullptr, n + 2u * stride); fold_frame<MEAN>(a, q3, h ? h + 3u * (size_t)npix : nullptr, n + 3u * stride);
         q += 4u * (size_t)plane_stride;
+        n += 4u * stride;
         if (h) h += 4u * (size_t)npix;
     }
     for (; f < frames; ++f) {
-        fold_frame(a, *q, f + 1u == frames ? (newest ? newest + p : nullptr) : h);
+        fold_frame<MEAN>(a, *q, f + 1u == frames ? (newest ? newest + p : nullptr) : h, n);
         q += plane_stride;
+        n += stride;
         if (h) h += npix;
     }
     accum[p] = a;
@@ -1040,13 +1136,17 @@ hipError_t pt_launch_path(const DevSceneF& sc, const DevCamF& cam, const PathArg
     KArgs k;
     k.sc = sc; k.cam = cam; k.a = a;
     k.a.width = cam.width; k.a.height = cam.height;
-    hipLaunchKernelGGL(path_kernel(nee, count, few), grid, block, 0, stream, k);
+    // dynamic LDS: the lane-parallel mode's image of the scene, laid out here (at most 64 + 64 + 3 * 64 rows = 5 KB)
+    const uint32_t ns = (uint32_t)sc.ns < 64u ? (uint32_t)sc.ns : 64u, np = (uint32_t)sc.np < 64u ? (uint32_t)sc.np : 64u, nt = (uint32_t)sc.nt < 64u ? (uint32_t)sc.nt : 64u;
+    const uint32_t f4s = few ? ns + np + 3u * nt : 0u;
+    k.a.lds_off_pla = ns; k.a.lds_off_tri = ns + np;
+    hipLaunchKernelGGL(path_kernel(nee, count, few), grid, block, f4s * 16u, stream, k);
     return hipGetLastError();
 }
 
 hipError_t pt_path_resident_blocks(bool nee, bool count, bool few, int device, uint32_t* blocks) {
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel(nee, count, few), PT_BLOCK, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_kernel(nee, count, few), PT_BLOCK, PT_LDS_MAX_BYTES);
     if (e != hipSuccess) return e;
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, device);
@@ -1063,8 +1163,9 @@ hipError_t pt_launch_resolve(const float4* accum, void* out, uint32_t npix, uint
 }
 
 hipError_t pt_launch_fold(float4* accum, const float4* planes, uint32_t plane_stride, uint32_t frames, uint32_t* newest,
-                          uint32_t* history, uint32_t npix, hipStream_t stream) {
-    hipLaunchKernelGGL(pt_fold_kernel, dim3((npix + 255u) / 256u), dim3(256), 0, stream, accum, planes, plane_stride, frames, newest, history, npix);
+                          uint32_t* history, uint32_t npix, uint32_t acc_mode, uint32_t s0, uint32_t stride, hipStream_t stream) {
+    if (acc_mode != 0u) hipLaunchKernelGGL(pt_fold_kernel<true>, dim3((npix + 255u) / 256u), dim3(256), 0, stream, accum, planes, plane_stride, frames, newest, history, npix, s0, stride);
+    else hipLaunchKernelGGL(pt_fold_kernel<false>, dim3((npix + 255u) / 256u), dim3(256), 0, stream, accum, planes, plane_stride, frames, newest, history, npix, s0, stride);
     return hipGetLastError();
 }
 

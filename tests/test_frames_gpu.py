@@ -1,0 +1,233 @@
+"""Frames in flight, second set (round 3): the reference's running mean inside multi-frame launches -- through pt_render
+and through launchRenderKernel itself --, the chains' buffers sized by what a launch holds, the serial fall-back when
+they cannot be allocated, frames with a side beyond 65 536 pixels, and the display history across a resize.
+Everything through the C ABI; the bar is bit-identity with the one-launch-per-frame loop."""
+import numpy as np
+import pytest
+
+from path_tracer_amd import abi, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from path_tracer_amd.renderer import Renderer
+    r = Renderer(0)
+    yield r
+    r.close()
+
+
+def _setup(r, scene, cam):
+    r.set_scene(scene)
+    r.set_camera(cam)
+    r.reset()
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_running_mean_frames_in_flight_match_serial(gpu, n):
+    """PT_ACC_RUNNING_MEAN frames (renderKernel's c*t + prev*(1-t), t = 1/(frame_count+1), raytracer_kernel.cu:297-304)
+    are collected into multi-frame launches like sums: the fold pass applies the recurrence frame after frame, so the
+    buffer and every frame's display are the serial loop's bit for bit."""
+    sc, cam = scenes.cuda_default(192, 108)
+    p = abi.render_params(acc_mode=abi.ACC_RUNNING_MEAN, fused_rgba8=1)
+    frames = 70   # one launch of 64 frames and one of 6
+    _setup(gpu, sc, cam)
+    serial_rgba = []
+    for f in range(frames):
+        gpu.render(f, 1, p)
+        serial_rgba.append(gpu.readback(abi.RESOLVE_RGBA8_CUDA))
+    serial = gpu.accum()
+    assert np.all(serial[..., 3] == 1.0)
+    gpu.set_frames_in_flight(n)
+    try:
+        _setup(gpu, sc, cam)
+        before = gpu.path_launches()
+        for f in range(frames):
+            gpu.render(f, 1, p)
+        got = gpu.accum()
+        assert gpu.path_launches() - before == 2
+        assert np.array_equal(got, serial)
+        assert np.array_equal(gpu.readback(abi.RESOLVE_RGBA8_CUDA), serial_rgba[-1])
+        assert gpu.history_frames() == 5
+        for back in range(1, 6):
+            assert np.array_equal(gpu.readback_history(back), serial_rgba[frames - 1 - back]), back
+        # frame_count == 0 in the middle of a run overwrites (the reference's only "reset"), also inside a launch
+        _setup(gpu, sc, cam)
+        q = abi.render_params(acc_mode=abi.ACC_RUNNING_MEAN)
+        for f in (0, 1, 2, 0, 1, 2, 3):
+            gpu.render(f, 1, q)
+        got = gpu.accum()
+        gpu.set_frames_in_flight(1)
+        _setup(gpu, sc, cam)
+        for f in (0, 1, 2, 0, 1, 2, 3):
+            gpu.render(f, 1, q)
+        assert np.array_equal(got, gpu.accum())
+        # sums and means alternate on one buffer: every change of mode starts a new launch
+        gpu.set_frames_in_flight(n)
+        _setup(gpu, sc, cam)
+        for f in range(3):
+            gpu.render(f, 1, q)
+        for f in range(3, 6):
+            gpu.render(f, 1, abi.render_params())
+        got = gpu.accum()
+        gpu.set_frames_in_flight(1)
+        _setup(gpu, sc, cam)
+        for f in range(3):
+            gpu.render(f, 1, q)
+        for f in range(3, 6):
+            gpu.render(f, 1, abi.render_params())
+        assert np.array_equal(got, gpu.accum())
+    finally:
+        gpu.set_frames_in_flight(1)
+
+
+def test_launch_render_kernel_collects_frames(gpu):
+    """The drop-in call itself: with frames in flight, consecutive launchRenderKernel calls on one `output` that the
+    caller does not read in between leave as ONE launch of the path kernel; after pt_flush `output` is the serial
+    loop's buffer bit for bit.  A caller that reads between launches (the reference's loop) flushes, and gets serial
+    launches."""
+    import torch
+    sc, cam = scenes.cuda_default(160, 90)
+    frames = 9
+    _setup(gpu, sc, cam)
+    out = torch.full((90, 160, 4), 7.0, device="cuda", dtype=torch.float32)   # frame_count == 0 overwrites
+    torch.cuda.synchronize()
+    for f in range(frames):
+        gpu.launch_render_kernel(out.data_ptr(), f)
+    gpu.sync()
+    serial = out.cpu().numpy()
+    gpu.set_frames_in_flight(2)
+    try:
+        out2 = torch.full((90, 160, 4), 7.0, device="cuda", dtype=torch.float32)
+        torch.cuda.synchronize()
+        before = gpu.path_launches()
+        for f in range(frames):
+            gpu.launch_render_kernel(out2.data_ptr(), f)
+        assert gpu.path_launches() == before          # all held back
+        gpu.flush()                                   # launches and folds them into `output`, on the context's stream
+        gpu.sync()
+        assert gpu.path_launches() - before == 1
+        assert np.array_equal(out2.cpu().numpy(), serial)
+        # the context's own buffer is bound again: the next pt_render does not touch `output`
+        gpu.reset()
+        gpu.render(0, 1, abi.render_params())
+        assert np.all(gpu.accum()[..., 3] == 1)
+        torch.cuda.synchronize()
+        assert np.array_equal(out2.cpu().numpy(), serial)
+        # two outputs in turn: a call that names another buffer first folds what the old one is owed
+        out3 = torch.zeros_like(out2)
+        out4 = torch.zeros_like(out2)
+        torch.cuda.synchronize()
+        for f in range(4):
+            gpu.launch_render_kernel(out3.data_ptr(), f)
+        for f in range(frames):
+            gpu.launch_render_kernel(out4.data_ptr(), f)
+        gpu.sync()
+        assert np.array_equal(out4.cpu().numpy(), serial)
+        assert np.all(out3.cpu().numpy()[..., 3] == 1.0) and not np.array_equal(out3.cpu().numpy(), serial)
+    finally:
+        gpu.set_frames_in_flight(1)
+
+
+@pytest.mark.parametrize("size", [(65537, 2), (3, 70001)])
+def test_frames_with_a_side_beyond_65536(gpu, size):
+    """alloc_frame admits any frame of up to 2^28 pixels; a lane's (x, y) of the next ray are packed with as many bits
+    as width and height need, for one-frame launches too (16 + 16 used to alias pixels of such frames)."""
+    sc, cam = scenes.cuda_default(*size)
+    q = abi.render_params(max_depth=4, fused_rgba8=1)
+    _setup(gpu, sc, cam)
+    for s in range(3):
+        gpu.render(s, 1, q)                       # serial one-frame launches
+    want = gpu.accum()
+    assert np.all(want[..., 3] == 3) and np.isfinite(want).all()
+    # every pixel got its own samples (aliased pixels would hold other pixels' samples too, and leave some untouched);
+    # and the multi-frame launch, which always packed by need, gives the same image
+    gpu.set_frames_in_flight(2)
+    try:
+        _setup(gpu, sc, cam)
+        for s in range(3):
+            gpu.render(s, 1, q)
+        assert np.array_equal(gpu.accum(), want)
+    finally:
+        gpu.set_frames_in_flight(1)
+    _setup(gpu, *scenes.cuda_default(64, 36))
+
+
+def test_display_history_does_not_survive_a_resize(gpu):
+    from path_tracer_amd._lib import PtError
+    sc, cam = scenes.cuda_default(96, 54)
+    _, cam_big = scenes.cuda_default(320, 180)
+    p = abi.render_params(fused_rgba8=1)
+    gpu.set_frames_in_flight(2)
+    try:
+        _setup(gpu, sc, cam)
+        for s in range(6):
+            gpu.render(s, 1, p)
+        assert gpu.history_frames() == 5
+        gpu.set_camera(cam_big)                   # a larger frame: the history planes were sized for the old one
+        assert gpu.history_frames() == 0
+        with pytest.raises(PtError, match="not held"):
+            gpu.readback_history(1)
+        for s in range(4):
+            gpu.render(s, 1, p)
+        assert gpu.history_frames() == 3
+        assert gpu.readback_history(3).shape == (180, 320)
+        gpu.set_camera(cam)                       # and a smaller one
+        assert gpu.history_frames() == 0
+        with pytest.raises(PtError, match="not held"):
+            gpu.readback_history(1)
+    finally:
+        gpu.set_frames_in_flight(1)
+
+
+def test_chain_buffers_are_sized_by_the_launch():
+    """A plain pt_render(ctx, 0, 16, ..) on a default context is one launch of 16 frames on one chain: it takes 16 planes
+    (236 MB at 1280x720), not 64 planes on each of three chains (2.8 GB)."""
+    import torch
+    from path_tracer_amd.renderer import Renderer
+    sc, cam = scenes.cuda_default(1280, 720)
+    r = Renderer(0)
+    try:
+        _setup(r, sc, cam)
+        r.render(0, 1, abi.render_params())
+        r.sync()
+        free0 = torch.cuda.mem_get_info()[0]
+        r.render(1, 16, abi.render_params(fused_rgba8=1))
+        r.sync()
+        taken = free0 - torch.cuda.mem_get_info()[0]
+        plane = 1280 * 720 * 16
+        assert taken <= 16 * plane + 15 * 1280 * 720 * 4 + (64 << 20), taken     # 16 planes + 15 history planes + allocator slack
+        assert np.all(r.accum()[..., 3] == 17)
+    finally:
+        r.close()
+
+
+def test_serial_fallback_when_the_chain_buffers_cannot_be_allocated(monkeypatch):
+    """No room for the planes of an overlapped launch: the frames are rendered by serial launches instead of being
+    dropped with PT_ERR_HIP -- same sums, same displays."""
+    from path_tracer_amd.renderer import Renderer
+    sc, cam = scenes.cuda_default(160, 90)
+    p = abi.render_params(fused_rgba8=1)
+    want = want_rgba = None
+    for fail in ("0", "1"):
+        monkeypatch.setenv("PT_AMD_FAIL_CHAIN_ALLOC", fail)
+        r = Renderer(0)
+        try:
+            _setup(r, sc, cam)
+            r.set_frames_in_flight(2)
+            before = r.path_launches()
+            for s in range(7):
+                r.render(s, 1, p)
+            r.render(7, 40, abi.render_params())        # a large call too (cut into frames)
+            acc, rgba = r.accum(), None
+            launches = r.path_launches() - before
+            if fail == "0":
+                want = acc
+                assert launches == 2
+            else:
+                assert launches == 7 + 20              # one per frame: 7 frames, then 20 frames of 2 samples
+                assert np.array_equal(acc, want)
+        finally:
+            r.close()
+    monkeypatch.delenv("PT_AMD_FAIL_CHAIN_ALLOC")

@@ -531,7 +531,7 @@ def test_frames_in_flight_match_serial(gpu, n):
         assert np.array_equal(runs[0], serial)
         assert np.array_equal(gpu.readback(abi.RESOLVE_RGBA8_CUDA), serial_rgba)        # the display of the last fold pass
         assert np.array_equal(gpu.resolve_to_host(abi.RESOLVE_RGBA8_CUDA), serial_rgba)
-        # a burst, a serial-only launch (running mean is never pipelined) and another burst
+        # a burst, a flush and another burst
         _setup(gpu, sc, cam)
         for s in range(5):
             gpu.render(s, 2, abi.render_params())        # 2 spp per launch

@@ -44,7 +44,8 @@ HEURISTIC_SCENES = {19: lambda w, h: scenes.cuda_default(w, h), 150: lambda w, h
 
 
 def _rate(env, scene, cam, depth, flight, frames, monkeypatch):
-    """Msamples/s of `frames` 1-spp frames (best of 4) on a fresh context created under `env`."""
+    """Msamples/s of `frames` 1-spp frames (median of 5 repetitions: the maximum of a handful of noisy timings is biased
+    upward, and the sweep below takes the best of ten such settings) on a fresh context created under `env`."""
     import time
     from path_tracer_amd.renderer import Renderer
     for k, v in env.items():
@@ -56,7 +57,7 @@ def _rate(env, scene, cam, depth, flight, frames, monkeypatch):
         _setup(r, scene, cam)
         r.set_frames_in_flight(flight)
         p = abi.render_params(max_depth=depth, fused_rgba8=1)
-        best = 0.0
+        rates = []
         for rep in range(6):      # the first repetition warms up (kernel load, chain buffers)
             r.sync()
             t = time.perf_counter()
@@ -65,8 +66,8 @@ def _rate(env, scene, cam, depth, flight, frames, monkeypatch):
             r.sync()
             dt = time.perf_counter() - t
             if rep:
-                best = max(best, cam.width * cam.height * frames / dt / 1e6)
-        return best
+                rates.append(cam.width * cam.height * frames / dt / 1e6)
+        return float(np.median(rates))
     finally:
         r.close()
 
@@ -76,9 +77,11 @@ def test_launch_heuristics_are_near_the_best_of_a_sweep(prims, monkeypatch):
     """pt_api.cpp chooses, per launch, the kernel build and threshold of the lane-parallel closest hit (few_max), the
     batch size of the regeneration (regen_min) and the grid; its rules were fitted on the Cornell box and on 4096
     spheres.  Here each choice is compared with a small sweep of its knob on scenes of 19, 150, 1 000 and 4 097
-    primitives, for serial one-frame launches and for frames in flight: the default must be within 10 % of the best
-    setting found.  (Timings of these short runs repeat to 3-6 % on a shared box, so a shortfall is measured a second
-    time, default and best setting again, before it counts; tools/heuristics_sweep.py prints the full tables.)"""
+    primitives, for serial one-frame launches and for frames in flight.  This is a guard against a GROSS misfit, not
+    the tuning record: the default's median rate must be within 20 % of the best median of the sweep (timings of
+    these short runs repeat to 3-6 % on a shared box, and a shortfall is measured a second time before it counts).
+    The tables the rules are fitted on come from tools/heuristics_sweep.py (profiles/r3_heuristics_sweep.json), and
+    tools/bench_sweep.sh carries the 150- and 1 000-primitive scenes so that a shift of an optimum shows as a number."""
     W, H = (1280, 720) if prims <= 150 else (640, 360)
     scene, cam = HEURISTIC_SCENES[prims](W, H)
     depth = 50 if prims == 19 else 16
@@ -95,10 +98,10 @@ def test_launch_heuristics_are_near_the_best_of_a_sweep(prims, monkeypatch):
         best = max(sweep, key=sweep.get)
         print(f"heuristics {prims} primitives, {mode}: " + ", ".join(f"{k} {v:.0f}" for k, v in sweep.items()))
         shortfall = 1.0 - base / sweep[best]
-        if shortfall >= 0.10:   # measure the pair again before believing it
+        if shortfall >= 0.20:   # measure the pair again before believing it
             k, v = best.rstrip("%").split("=")
             again_best = _rate({knobs[k]: v}, scene, cam, depth, flight, frames, monkeypatch)
             again_base = _rate({}, scene, cam, depth, flight, frames, monkeypatch)
             print(f"  again: default {again_base:.0f}, {best} {again_best:.0f}")
             shortfall = min(shortfall, 1.0 - max(base, again_base) / again_best)
-        _bound(f"heuristics_{prims}_{mode}/shortfall_of_default_vs_best({best})", shortfall, 0.10)
+        _bound(f"heuristics_{prims}_{mode}/shortfall_of_default_vs_best({best})", shortfall, 0.20)

@@ -33,7 +33,8 @@ def test_no_alloc_entry_point_matches_pt_render():
         sc, cam = scenes.cuda_default(320, 180)
         r.set_scene(sc)
         r.set_camera(cam)
-        r.render(0, 8, p)                       # the existing entry point (a single launch: < 12 samples)
+        r.render(0, 8, p)                       # the existing entry point (it cuts the call into 8 one-sample frames of one launch and
+                                                #  adds them to a zero buffer in sample order: the same float adds as one 8-sample launch)
         want_big = r.accum()
         free_before = torch.cuda.mem_get_info()[0]
         r.render_noalloc(big.data_ptr(), 0, 8, p)

@@ -1,15 +1,17 @@
 """Per-wave timeline of one launch (needs a PT_TRACE kernel build: make variant NAME=trace VFLAGS="-DPT_TRACE").
-python tools/gpu_trace.py [few_max]"""
+python tools/gpu_trace.py [few_max|-] [variant library name, default trace] [serial: only the one-frame 720p launch]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-os.environ["PT_AMD_LIB"] = os.path.join(ROOT, "path_tracer_amd", "lib", "libpt_amd_trace.so")
+os.environ["PT_AMD_LIB"] = os.path.join(ROOT, "path_tracer_amd", "lib", f"libpt_amd_{sys.argv[2] if len(sys.argv) > 2 else 'trace'}.so")
 os.environ["PT_AMD_TRACE"] = "/tmp/pt_trace.bin"
-if len(sys.argv) > 1: os.environ["PT_AMD_FEW_MAX"] = sys.argv[1]
+if len(sys.argv) > 1 and sys.argv[1] != "-": os.environ["PT_AMD_FEW_MAX"] = sys.argv[1]
+CASES = (("cuda_default", (1280, 720), 1, 1), ("cuda_default", (1280, 720), 1, 20), ("cuda_default", (3840, 2160), 16, 1))
+if len(sys.argv) > 3 and sys.argv[3] == "serial": CASES = CASES[:1]
 import numpy as np
 from path_tracer_amd import abi, scenes
 from path_tracer_amd.renderer import Renderer
 r = Renderer(0)
-for name, (w, h), spp, frames in (("cuda_default", (1280, 720), 1, 1), ("cuda_default", (1280, 720), 1, 20), ("cuda_default", (3840, 2160), 16, 1)):
+for name, (w, h), spp, frames in CASES:
     sc, cam = scenes.builtin(name, w, h)
     r.set_frames_in_flight(1); r.set_scene(sc); r.set_camera(cam); r.reset()
     r.set_frames_in_flight(3 if frames > 1 else 1)      # frames > 1: one launch of that many frames (the last launch is traced)
@@ -43,6 +45,10 @@ for name, (w, h), spp, frames in (("cuda_default", (1280, 720), 1, 1), ("cuda_de
     for i in late:
         fe = (end[i] - few[i]) if t[i, 2] > 0 else 0.0
         print(f"     late wave: end {end[i]:.1f} exh {exh[i]:.1f} few-start {few[i]:.1f} trips {int(trips[i])} few-trips {int(ftrips[i])} -> {fe / max(ftrips[i], 1):.3f} us per few-trip")
+        ft = max(ftrips[i], 1); nt = max(trips[i] - ftrips[i], 1)
+        tc, tf = t[i, 8:11].astype(np.float64), t[i, 11:14].astype(np.float64)
+        print(f"        cycles per few-trip: regen {tf[0] / ft:.0f} isect {tf[1] / ft:.0f} shade {tf[2] / ft:.0f};  per normal trip: regen {(tc[0] - tf[0]) / nt:.0f} isect {(tc[1] - tf[1]) / nt:.0f} shade {(tc[2] - tf[2]) / nt:.0f};"
+              f"  all cycles {tc.sum():.0f} over {end[i] - start[i]:.1f} us = {tc.sum() / max(end[i] - start[i], 1e-9) / 1e3:.2f} GHz; few rays {int(frays[i])}")
     # how much of the chip is busy over time
     grid = np.linspace(0, end.max(), 21)
     act = [(int(((start <= g) & (end > g)).sum())) for g in grid]
