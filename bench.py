@@ -43,6 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (vector), spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # the FP64 vector rate is half the FP32 vector rate on CDNA (v_fma_f64 issues over twice the cycles); AMD's MI355X figure
 
 WORKLOADS = {
     # name: (scene, width, height, spp per step, max_depth)
@@ -71,6 +72,7 @@ def main() -> int:
                     help="headline leg only. weak: every rank renders K steps (default, the driver's contract); strong: the K "
                          "steps are divided among the ranks")
     ap.add_argument("--no-4k-leg", action="store_true", help="leave out the 4K / 1024 spp strong-scaling leg (BASELINE config 3)")
+    ap.add_argument("--no-direct-leg", action="store_true", help="leave out the FP64 `direct` leg (BASELINE config 1: cpu_default, 1280x720, 64 spp; N = 1 only)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks over gloo, all on GPU 0: exercises the multi-rank code path on a one-GPU box (the "
                          "numbers mean nothing)")
@@ -235,11 +237,74 @@ def main() -> int:
         out["_scene"], out["_cam"], out["_params"] = scene, cam, params
         return out
 
+    def run_direct_leg(steps=4, cpu_seconds=4.0):
+        """BASELINE config 1: the CPU program's own scene and integrator (cpu_pathtracer/src/main.cpp:14-53,63-131) on the GPU, FP64:
+        cpu_default, 1280x720, one step = one pt_render call of 64 spp; the oracle's restatement of renderRegion beside it."""
+        from path_tracer_amd.renderer import direct_flops
+        W, H, spp = 1280, 720, 64
+        scene, cam = scenes.cpu_default(W, H)
+        p = abi.render_params(integrator=abi.INTEGRATOR_DIRECT)
+        if r._bound is not None:
+            r.unbind()
+        r.set_frames_in_flight(1)
+        r.set_scene(scene)
+        r.set_camera(cam)
+        r.reset()
+        r.render(0, spp, p)   # warm-up: loads the kernel
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for k in range(steps):
+            r.render((1 + k) * spp, spp, p)
+        ev1.record()
+        r.resolve(abi.RESOLVE_RGBA8_CPU)    # the CPU app's accumulate + gamma + pack (main.cpp:223-237)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = ev0.elapsed_time(ev1) / steps
+        w = r.accum()[..., 3]
+        if float(w.min()) != (steps + 1) * spp or float(w.max()) != (steps + 1) * spp:
+            raise RuntimeError("direct leg: wrong sample count in the accumulation buffer")
+        r.reset_counters()
+        r.render(spp, spp, abi.render_params(integrator=abi.INTEGRATOR_DIRECT, flags=abi.FLAG_COUNTERS))
+        cnt = r.counters().as_dict()
+        flops = direct_flops(cnt, scene.num_spheres, scene.num_planes, scene.num_triangles, W * H)
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        leg = {"baseline_config": 1, "metric": "Msamples/s", "value": round(steps * W * H * spp / elapsed / 1e6, 3), "n_gpus": 1,
+               "scene": "cpu_default", "integrator": "direct", "dtype": "f64", "width": W, "height": H, "spp_per_step": spp, "steps": steps, "warmup": 1,
+               "ms_per_step": round(elapsed / steps * 1e3, 4), "mrays_per_s": round(steps * W * H * spp / elapsed / 1e6 * cnt["rays"] / cnt["samples"], 1),
+               "rays_per_sample": round(cnt["rays"] / cnt["samples"], 4),
+               "roofline": {"bound": "valu_fp64", "kernel": "pt_direct_kernel", "achieved": round(achieved, 4), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(achieved / FP64_VALU_PEAK_TFLOPS, 5), "traffic": None, "flops_per_launch": flops,
+                            "flops_per_sample": round(flops / (W * H * spp), 1), "kernel_ms": round(kernel_ms, 4)}}
+        if cpu_seconds > 0:
+            from tests.oracle_binding import load_oracle
+            o = load_oracle()
+            t = time.perf_counter()
+            acc = o.render_direct(scene, cam, 0, 1, p)
+            one = time.perf_counter() - t
+            n = max(1, min(64, int(cpu_seconds / max(one, 1e-3))))
+            t = time.perf_counter()
+            o.render_direct(scene, cam, 1, n, p, accum=acc)
+            dt = time.perf_counter() - t
+            try:
+                import ctypes as C
+                cores = int(C.CDLL("libgomp.so.1").omp_get_max_threads())
+            except OSError:
+                cores = os.cpu_count() or 1
+            leg["cpu_baseline"] = {"value": round(W * H * n / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                                   "sample": f"{n} spp of {W}x{H} ({W * H * n} samples, {dt:.1f} s), oracle/libpt_oracle.so pto_render_direct "
+                                             "(the restatement of renderRegion, FP64, OpenMP over rows)"}
+        return leg
+
     try:
         head = run_leg(args.workload, args.steps, args.warmup, args.scaling, serial_probe=True)
         leg4k = None
         if not args.no_4k_leg and not args.mis:
             leg4k = run_leg(LEG_4K[0], LEG_4K[1], LEG_4K[2], "strong", serial_probe=False)
+        leg_direct = None
+        if world == 1 and not args.no_direct_leg and not args.mis:
+            leg_direct = run_direct_leg(cpu_seconds=min(4.0, args.cpu_seconds))
     except RuntimeError as e:
         print(f"bench.py: {e}", file=sys.stderr)
         return 3
@@ -296,6 +361,8 @@ def main() -> int:
                 "wall_ms": round(l["elapsed_s"] * 1e3, 3), "render_ms": round(l["render_ms"], 3), "reduce_ms": round(l["reduce_ms"], 3),
                 "reduce_bytes": l["width"] * l["height"] * 16 if world > 1 else 0, "frames_in_flight": l["frames_in_flight"],
                 "roofline": roofline(l, False)}}
+        if leg_direct:
+            result.setdefault("legs", {})["cpu_default_direct_720p_64spp"] = leg_direct
         if world == 1 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(head["_scene"], head["_cam"], head["_params"], head["spp_per_step"], args.cpu_seconds)
     if world > 1:

@@ -353,6 +353,13 @@ int pt_primary_ids(PtContext* ctx, uint32_t* host_obj_ids, uint32_t* host_mat_id
  * pt_reset_counters.  Synchronises. */
 int pt_counters(PtContext* ctx, PtCounters* out);
 int pt_reset_counters(PtContext* ctx);
+/* Samples by path length, accumulated with the counters (PT_FLAG_COUNTERS; cleared by pt_reset_counters):
+ * out_bins[k], k < PT_HISTOGRAM_BINS, is the number of camera paths that traced k rays -- one per iteration of
+ * traceRay's loop (raytracer_kernel.cu:206-208), shadow rays apart; the last bin also holds every longer path.
+ * Sum of bins = PtCounters.samples, sum of k * bins[k] = rays - shadow_rays (max_depth < PT_HISTOGRAM_BINS).
+ * This is the "bounce histogram" of SURVEY §8(d).4: the divergence the lanes of a wave see.  Synchronises. */
+#define PT_HISTOGRAM_BINS 64u
+int pt_path_length_histogram(PtContext* ctx, uint64_t* out_bins);
 /* FP32 VALU ceiling micro-benchmark: runs `iters` dependent-chain FMA rounds on
  * every lane of a full-chip grid; packed != 0 uses v_pk_fma_f32.  Returns the
  * achieved TFLOP/s in *out_tflops.  Synchronises. */

@@ -155,6 +155,39 @@ int pto_render_path(const PtSceneSoA* sc, const PtCamera* cam, uint32_t y0, uint
     return PT_OK;
 }
 
+/* Path lengths: the rays a sample traces are the iterations of traceRay's loop (raytracer_kernel.cu:206-208), read
+ * here off the event counters (rays - shadow_rays) before and after the sample. */
+int pto_path_length_histogram(const PtSceneSoA* sc, const PtCamera* cam, uint32_t s0, uint32_t n, const PtRenderParams* prm,
+                              int precision, uint64_t* hist64) {
+    if (!sc || !cam || !prm || !hist64 || (precision != 32 && precision != 64)) return PT_ERR_INVALID;
+    LightList ll;
+    if (build_lights(sc, &ll)) return PT_ERR_INVALID;
+    f32_Ctx c32 = {sc, ll.nlights, ll.light_sphere, ll.sphere_light, prm->flags, prm->max_depth, prm->rr_depth};
+    f64_Ctx c64 = {sc, ll.nlights, ll.light_sphere, ll.sphere_light, prm->flags, prm->max_depth, prm->rr_depth};
+    f32_Cam k32 = f32_make_cam(cam);
+    f64_Cam k64 = f64_make_cam(cam);
+    memset(hist64, 0, 64 * sizeof(uint64_t));
+#pragma omp parallel
+    {
+        uint64_t local[64]; memset(local, 0, sizeof local);
+        PtCounters c; memset(&c, 0, sizeof c);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t y = 0; y < (int64_t)cam->height; y++)
+            for (uint32_t x = 0; x < cam->width; x++)
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint64_t before = c.rays - c.shadow_rays;
+                    if (precision == 32) (void)f32_sample(&c32, &k32, x, (uint32_t)y, s0 + i, prm->seed, &c);
+                    else (void)f64_sample(&c64, &k64, x, (uint32_t)y, s0 + i, prm->seed, &c);
+                    const uint64_t len = c.rays - c.shadow_rays - before;
+                    local[len < 63 ? len : 63]++;
+                }
+#pragma omp critical
+        for (int k = 0; k < 64; k++) hist64[k] += local[k];
+    }
+    free_lights(&ll);
+    return PT_OK;
+}
+
 int pto_path_sample(const PtSceneSoA* sc, const PtCamera* cam, uint32_t x, uint32_t y, uint32_t s,
                     const PtRenderParams* prm, int precision, double* rgb) {
     if (!sc || !cam || !prm || !rgb) return PT_ERR_INVALID;
@@ -380,6 +413,59 @@ int pto_primary_ids(const PtSceneSoA* sc, const PtCamera* cam, uint32_t* obj_ids
             size_t p = (size_t)y * cam->width + x;
             if (obj_ids) obj_ids[p] = h.hit ? h.obj : 0xFFFFFFFFu;
             if (mat_ids) mat_ids[p] = h.hit ? h.mat : 0xFFFFFFFFu;
+        }
+    return PT_OK;
+}
+
+/* Rectangle::intersect, cpu_pathtracer/include/Polygon.h:103-153 (the CUDA class has the same body in float,
+ * cuda_pathtracer/include/Polygon.cuh:130-168): the plane of the rectangle, then the hit point projected on the two
+ * edges separately, alpha = (h . u) / (u . u) and beta = (h . v) / (v . v), both in [0, 1].  Statement order and
+ * constants as in the CPU class; the distance test is the ray's own (dvalid), as for every other object here. */
+static DHit drect(const double* o9, uint32_t obj, uint32_t mat, const DRay* ray) {
+    DHit h; memset(&h, 0, sizeof h);
+    D3 origin = d3(o9[0], o9[1], o9[2]), u = d3(o9[3], o9[4], o9[5]), v = d3(o9[6], o9[7], o9[8]);
+    D3 normal = dnormalized(dcross(u, v));                 /* computeNormal, :115-117 */
+    const double denom = ddot(normal, ray->d);
+    if (fabs(denom) < 1e-8) return h;                      /* :124-125 */
+    D3 p0_ro = dsub(origin, ray->o);
+    const double t = ddot(p0_ro, normal) / denom;          /* :127-128 */
+    if (!dvalid(ray, t)) return h;                         /* :130-131 */
+    D3 hit_point = dadd(ray->o, dmul(ray->d, t));
+    D3 hit_vec = dsub(hit_point, origin);
+    const double alpha = ddot(hit_vec, u) / ddot(u, u);    /* :138-139 */
+    const double beta = ddot(hit_vec, v) / ddot(v, v);
+    if (alpha < 0.0 || alpha > 1.0 || beta < 0.0 || beta > 1.0) return h;   /* :142-143 */
+    h.hit = 1; h.t = t; h.p = hit_point; h.obj = obj; h.mat = mat; h.kind = 3; h.prim = 0;
+    dface(&h, ray, normal);
+    return h;
+}
+
+/* pto_primary_ids for a scene whose rectangles are tested by the reference's own formula instead of through the two
+ * triangles the host flattens them to: the triangles whose object id is one of rect_obj[] are skipped and the
+ * rectangle (origin, u, v: 9 doubles each) stands in their place.  Pins the flattening (include/pt_host.hpp,
+ * path_tracer_amd/scenes.py) against Rectangle::intersect: the two id maps may differ only where a ray meets the
+ * rectangle's border or the diagonal its triangles share, within rounding. */
+int pto_primary_ids_rect(const PtSceneSoA* sc, const PtCamera* cam, uint32_t n_rect, const double* rect_o_u_v,
+                         const uint32_t* rect_obj, const uint32_t* rect_mat, uint32_t* obj_ids, uint32_t* mat_ids) {
+    if (!sc || !cam || (n_rect && (!rect_o_u_v || !rect_obj || !rect_mat))) return PT_ERR_INVALID;
+    DCam k = make_dcam(cam);
+#pragma omp parallel for schedule(static)
+    for (int64_t y = 0; y < (int64_t)cam->height; y++)
+        for (uint32_t x = 0; x < cam->width; x++) {
+            DRay r = dcam_ray(&k, x, (uint32_t)y, 0.5, 0.5);
+            DHit best; memset(&best, 0, sizeof best);
+            for (uint32_t i = 0; i < sc->num_spheres; i++) { DHit h = dsphere(sc, i, &r); dconsider(&best, &h); }
+            for (uint32_t i = 0; i < sc->num_planes; i++) { DHit h = dplane(sc, i, &r); dconsider(&best, &h); }
+            for (uint32_t i = 0; i < sc->num_triangles; i++) {
+                int of_a_rectangle = 0;
+                for (uint32_t q = 0; q < n_rect; q++) of_a_rectangle |= sc->tri_obj[i] == rect_obj[q];
+                if (of_a_rectangle) continue;
+                DHit h = dtri(sc, i, &r); dconsider(&best, &h);
+            }
+            for (uint32_t q = 0; q < n_rect; q++) { DHit h = drect(rect_o_u_v + 9 * q, rect_obj[q], rect_mat[q], &r); dconsider(&best, &h); }
+            size_t p = (size_t)y * cam->width + x;
+            if (obj_ids) obj_ids[p] = best.hit ? best.obj : 0xFFFFFFFFu;
+            if (mat_ids) mat_ids[p] = best.hit ? best.mat : 0xFFFFFFFFu;
         }
     return PT_OK;
 }

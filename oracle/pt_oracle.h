@@ -46,6 +46,13 @@ uint32_t pto_draw(uint32_t key, uint32_t slot, uint32_t dim);
 /* Primary-hit object / material ids through pixel centres, FP64. */
 int pto_primary_ids(const PtSceneSoA* scene, const PtCamera* cam, uint32_t* obj_ids, uint32_t* mat_ids);
 
+/* The same with the scene's rectangles tested by Rectangle::intersect (cpu_pathtracer/include/Polygon.h:103-153,
+ * cuda_pathtracer/include/Polygon.cuh:130-168: plane hit, then alpha / beta in [0, 1]) in place of the triangles the
+ * host flattens them to: rect_o_u_v holds origin, u, v (9 doubles) per rectangle, rect_obj / rect_mat its object and
+ * material ids; triangles of the scene whose object id is in rect_obj are skipped. */
+int pto_primary_ids_rect(const PtSceneSoA* scene, const PtCamera* cam, uint32_t n_rect, const double* rect_o_u_v,
+                         const uint32_t* rect_obj, const uint32_t* rect_mat, uint32_t* obj_ids, uint32_t* mat_ids);
+
 /* `direct` integrator (renderRegion): adds samples [s0, s0+n) of every pixel of
  * rows [y0, y1) to accum (float4 per pixel: sum r,g,b and sample count). */
 int pto_render_direct(const PtSceneSoA* scene, const PtCamera* cam, uint32_t y0, uint32_t y1,
@@ -61,6 +68,10 @@ int pto_direct_components(const PtSceneSoA* scene, const PtCamera* cam, uint32_t
 int pto_render_path(const PtSceneSoA* scene, const PtCamera* cam, uint32_t y0, uint32_t y1,
                     uint32_t s0, uint32_t n, const PtRenderParams* params, int precision,
                     float* accum, PtCounters* counters);
+/* Samples [s0, s0+n) of every pixel by path length: hist[k], k < 64, counts the paths that traced k rays (iterations of
+ * traceRay's loop, raytracer_kernel.cu:206-208; shadow rays apart), the last bin every longer one. */
+int pto_path_length_histogram(const PtSceneSoA* scene, const PtCamera* cam, uint32_t s0, uint32_t n,
+                              const PtRenderParams* params, int precision, uint64_t* hist64);
 /* Radiance of one sample of one pixel, double[3] (for targeted tests). */
 int pto_path_sample(const PtSceneSoA* scene, const PtCamera* cam, uint32_t x, uint32_t y, uint32_t s,
                     const PtRenderParams* params, int precision, double* rgb);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "pt_readback_accum", "pt_history_frames", "pt_readback_history", "pt_upload_accum", "pt_sync", "pt_accum_device_ptr", "pt_display_device_ptr",
     "pt_primary_ids", "pt_counters", "pt_reset_counters", "pt_valu_peak", "pt_make_current",
     "launchRenderKernel", "pt_builtin_scene", "pt_set_frames_in_flight", "pt_frames_in_flight", "pt_path_launches", "pt_flush",
-    "pt_fly_camera_step", "pt_reduce", "pt_render_noalloc",
+    "pt_fly_camera_step", "pt_reduce", "pt_render_noalloc", "pt_path_length_histogram",
 ]
 
 _lib = None
@@ -78,6 +78,7 @@ def lib() -> C.CDLL:
     L.pt_primary_ids.argtypes = [ctx, vp, vp]
     L.pt_counters.argtypes = [ctx, C.POINTER(abi.PtCounters)]
     L.pt_reset_counters.argtypes = [ctx]
+    L.pt_path_length_histogram.argtypes = [ctx, vp]
     L.pt_valu_peak.argtypes = [ctx, u32, u32, C.POINTER(C.c_double)]
     L.pt_make_current.argtypes = [ctx]
     L.launchRenderKernel.argtypes = [vp, u32, u32, u32, abi.PtDim3, abi.PtDim3]  # grid, block by value, like dim3

@@ -82,7 +82,7 @@ struct PtContext {
     void* display = nullptr;  // 16 B / pixel: large enough for every resolve mode
     size_t display_bytes = 0;  // bytes the last resolve produced
     uint32_t last_acc_mode = PT_ACC_SUM;
-    uint64_t* counters = nullptr;  // 12 x u64
+    uint64_t* counters = nullptr;  // 12 x u64, then 64 copies of the 64 x u64 path-length histogram (one allocation)
     uint32_t* ids = nullptr;       // 2 * npix, allocated on demand
     float* sink = nullptr;
     uint32_t* work_counter = nullptr;  // ticket counters of the path kernel: 8 chains x 2 alternating sets x 8 shards x 128 B
@@ -453,6 +453,7 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     a.rgba = (prm->fused_rgba8 && !pipelined) ? (uint32_t*)ctx->display : nullptr;
     if (a.rgba) ctx->history_frames = 0;  // (the display no longer continues the history planes)
     a.counters = (prm->flags & PT_FLAG_COUNTERS) ? ctx->counters : nullptr;
+    a.hist = a.counters ? ctx->counters + 12 : nullptr;
     a.s0 = sample_begin; a.count = sample_count;
     a.frames = frames; a.plane_stride = ctx->width * ctx->height; a.frame_stride = frame_stride;
     // (x, y, frame) of a lane's next ray in one register: as many bits as each needs (a frame is at most 2^28 pixels, so
@@ -688,8 +689,8 @@ int pt_create(int device_id, PtContext** out) {
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(PT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     ctx->stream = ctx->own_stream;
-    e = hipMalloc((void**)&ctx->counters, 12 * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMemset(ctx->counters, 0, 12 * sizeof(uint64_t));
+    e = hipMalloc((void**)&ctx->counters, (12 + 64 * PT_HISTOGRAM_BINS) * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemset(ctx->counters, 0, (12 + 64 * PT_HISTOGRAM_BINS) * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->sink, 256);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->work_counter, 2 * PT_MAX_CHAINS * WORK_SET_WORDS * 4);
     if (e == hipSuccess) e = hipMemset(ctx->work_counter, 0, 2 * PT_MAX_CHAINS * WORK_SET_WORDS * 4);
@@ -1045,7 +1046,8 @@ static int render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, 
     if (prm->integrator == PT_INTEGRATOR_DIRECT) {
         if (prm->acc_mode != PT_ACC_SUM) return fail(PT_ERR_INVALID, "the direct integrator accumulates sums only");
         if (int rc = join_chains(ctx)) return rc;
-        HIP_TRY(pt_launch_direct(ctx->sd, ctx->cd, ctx->accum, sample_begin, sample_count, prm->seed, ctx->stream));
+        HIP_TRY(pt_launch_direct(ctx->sd, ctx->cd, ctx->accum, sample_begin, sample_count, prm->seed,
+                                 (prm->flags & PT_FLAG_COUNTERS) ? ctx->counters : nullptr, ctx->stream));
         ctx->last_acc_mode = PT_ACC_SUM;
         return PT_OK;
     }
@@ -1251,7 +1253,21 @@ int pt_counters(PtContext* ctx, PtCounters* out) {
 int pt_reset_counters(PtContext* ctx) {
     if (int rc = use(ctx)) return rc;
     if (int rc = join_chains(ctx)) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->counters, 0, 12 * sizeof(uint64_t), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->counters, 0, (12 + 64 * PT_HISTOGRAM_BINS) * sizeof(uint64_t), ctx->stream));
+    return PT_OK;
+}
+
+int pt_path_length_histogram(PtContext* ctx, uint64_t* out_bins) {
+    if (int rc = use(ctx)) return rc;
+    if (!out_bins) return fail(PT_ERR_INVALID, "out_bins is null");
+    if (int rc = join_chains(ctx)) return rc;
+    std::vector<uint64_t> copies(64 * PT_HISTOGRAM_BINS);   // the kernel keeps 64 copies (one per blockIdx % 64)
+    HIP_TRY(hipMemcpyAsync(copies.data(), ctx->counters + 12, copies.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (uint32_t b = 0; b < PT_HISTOGRAM_BINS; ++b) {
+        out_bins[b] = 0;
+        for (uint32_t c = 0; c < 64u; ++c) out_bins[b] += copies[c * PT_HISTOGRAM_BINS + b];
+    }
     return PT_OK;
 }
 

@@ -48,6 +48,7 @@ struct PathArgs {
     float4* accum;
     uint32_t* rgba;          // display buffer (fused resolve) or nullptr
     uint64_t* counters;      // 12 x u64 (PtCounters order) or nullptr
+    uint64_t* hist;          // 64 copies x 64 x u64: samples by the number of path rays they traced (instrumented builds) or nullptr
     uint32_t* work_counter;  // this launch's 8 ticket counters on separate 128-B lines (word 32*s), zero at start
     uint32_t* next_counter;  // the chain's other set: zeroed by this launch for the chain's next one
     float total_w, inv_total_w;  // (float)(s0 + count) and its reciprocal, for the fused display pack
@@ -130,5 +131,6 @@ hipError_t pt_launch_fold(float4* accum, const float4* planes, uint32_t plane_st
 hipError_t pt_launch_valu_peak(float* sink, uint32_t packed, uint32_t iters, uint32_t blocks, hipStream_t stream);
 hipError_t pt_launch_primary_ids(const DevSceneD& sc, const DevCamD& cam, uint32_t* obj, uint32_t* mat,
                                  hipStream_t stream);
+// counters != nullptr: the instrumented build, which adds samples / rays / hits / light samples / shadow rays to the PtCounters block
 hipError_t pt_launch_direct(const DevSceneD& sc, const DevCamD& cam, float4* accum, uint32_t s0, uint32_t count,
-                            uint32_t seed, hipStream_t stream);
+                            uint32_t seed, uint64_t* counters, hipStream_t stream);

@@ -142,16 +142,21 @@ __device__ bool visible(const DevSceneD& sc, D3 from, D3 to) {
 
 // renderRegion, cpu_pathtracer/src/main.cpp:14-53: ambient 0.1 + (emission | one sample per
 // light * colour*cos*50/d^2), background 0.2.  One thread = one pixel, samples in a loop.
+// COUNT: the instrumented build (PT_FLAG_COUNTERS) adds its event counts to `counters` (PtCounters layout): samples,
+// rays (primary + shadow), hits (primary), nee_samples (light samples drawn), shadow_rays (Scene::isVisible calls).
+template <bool COUNT>
 __global__ __launch_bounds__(256) void pt_direct_kernel(const DevSceneD sc, const DevCamD cam, float4* accum, uint32_t s0,
-                                                        uint32_t count, uint32_t seed) {
+                                                        uint32_t count, uint32_t seed, uint64_t* counters) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= cam.width * cam.height) return;
     const uint32_t y = p / cam.width, x = p - y * cam.width;
     double px[3] = {0, 0, 0};
+    uint32_t c_hits = 0, c_lights = 0, c_shadow = 0;
     for (uint32_t i = 0; i < count; ++i) {
         const uint32_t key = pt_hash(pt_hash(pt_hash(seed) + p) + (s0 + i));
         const DRay ray = camera_ray(cam, x, y, duni(pt_draw(key, 0, 0)), duni(pt_draw(key, 0, 1)));
         const DHit h = scene_hit(sc, ray);
+        if (COUNT) c_hits += h.hit ? 1u : 0u;
         if (!h.hit) { px[0] += 0.2; px[1] += 0.2; px[2] += 0.2; continue; }
         px[0] += 0.1; px[1] += 0.1; px[2] += 0.1;
         if (h.kind == 0 && sc.sph_info[3 * h.prim + 2] != 0u) {
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(256) void pt_direct_kernel(const DevSceneD sc, cons
             if (sc.sph_info[3 * l + 2] == 0u) continue;
             const double u = duni(pt_draw(key, 1 + light, 0)), v = duni(pt_draw(key, 1 + light, 1));
             light++;
+            if (COUNT) c_lights++;
             // Sphere::getRandomPoint, ImplicitObject.h:111-125
             const double theta = 2.0 * M_PI * u;
             const double phi = acos(2.0 * v - 1.0);
@@ -186,6 +192,7 @@ __global__ __launch_bounds__(256) void pt_direct_kernel(const DevSceneD sc, cons
             const D3 lp = d3(s[0], s[1], s[2]) + dir * s[3];
             const D3 light_dir = normalized(lp - hp);
             const double cos_theta = fmax(0.0, dot(n, light_dir));
+            if (COUNT) c_shadow += cos_theta > 0 ? 1u : 0u;
             if (cos_theta > 0 && visible(sc, hp, lp)) {
                 const double ld = length(lp - hp);
                 const double att = 1.0 / (ld * ld);
@@ -197,6 +204,13 @@ __global__ __launch_bounds__(256) void pt_direct_kernel(const DevSceneD sc, cons
     float4 a = accum[p];
     a.x += (float)px[0]; a.y += (float)px[1]; a.z += (float)px[2]; a.w += (float)count;
     accum[p] = a;
+    if (COUNT && counters) {   // PtCounters: [0] samples, [1] rays, [2] hits, [10] nee_samples, [11] shadow_rays
+        atomicAdd((unsigned long long*)&counters[0], (unsigned long long)count);
+        atomicAdd((unsigned long long*)&counters[1], (unsigned long long)(count + c_shadow));
+        atomicAdd((unsigned long long*)&counters[2], (unsigned long long)c_hits);
+        atomicAdd((unsigned long long*)&counters[10], (unsigned long long)c_lights);
+        atomicAdd((unsigned long long*)&counters[11], (unsigned long long)c_shadow);
+    }
 }
 
 }  // namespace
@@ -208,8 +222,9 @@ hipError_t pt_launch_primary_ids(const DevSceneD& sc, const DevCamD& cam, uint32
 }
 
 hipError_t pt_launch_direct(const DevSceneD& sc, const DevCamD& cam, float4* accum, uint32_t s0, uint32_t count,
-                            uint32_t seed, hipStream_t stream) {
+                            uint32_t seed, uint64_t* counters, hipStream_t stream) {
     const uint32_t n = cam.width * cam.height;
-    hipLaunchKernelGGL(pt_direct_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, cam, accum, s0, count, seed);
+    if (counters) hipLaunchKernelGGL(pt_direct_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, stream, sc, cam, accum, s0, count, seed, counters);
+    else hipLaunchKernelGGL(pt_direct_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, stream, sc, cam, accum, s0, count, seed, counters);
     return hipGetLastError();
 }

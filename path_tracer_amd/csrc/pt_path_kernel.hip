@@ -589,6 +589,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
     int expect = -1;
     float prev_pdf_b = -1.0f;
     // counters (instrumented build only)
+    uint32_t c_path_rays = 0;   // path rays of the lane's current sample (shadow rays apart): the histogram's bin
     uint32_t c_samples = 0, c_rays = 0, c_hits = 0, c_roots = 0, c_b0 = 0, c_b1 = 0, c_b2 = 0, c_b3 = 0, c_b4 = 0,
              c_diff = 0, c_nee = 0, c_shadow = 0;
     const bool need_prev = a.overwrite == 0u && (a.acc_mode == 0u || a.s0 > 0u);
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
             // (miss and hit are two regions side by side, not an if/else inside `if (alive)`: one nesting
             //  level fewer for hipcc to copy the lane state around)
             const float t = t_hit; const int id = id_hit;
-            if (COUNT) { if (alive) { c_rays++; if (id >= 0) c_hits++; } }
+            if (COUNT) { if (alive) { c_rays++; if (id >= 0) c_hits++; if (!(NEE && shadow)) c_path_rays++; } }
             bool end_path = false;
             if (alive && id < 0) {
                 // miss: black background (:208); an escaping shadow ray reached no light
@@ -802,7 +803,11 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
                     if (!(NEE && shadow) && depth >= a.max_depth) end_path = true;
                 }
             }
-            if (end_path) { sum = sum + L; alive = false; cur_left--; }
+            if (end_path) {
+                sum = sum + L; alive = false; cur_left--;
+                // (64 copies of the histogram, one per blockIdx % 64, summed by the host: one copy's 64 hot words serialise the atomics)
+                if (COUNT) { if (a.hist) atomicAdd((unsigned long long*)&a.hist[(blockIdx.x & 63u) * 64u + min(c_path_rays, 63u)], 1ull); }
+            }
         }
         PT_SECTION(_shade)
         }
@@ -957,6 +962,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
             depth = 0;
             alive = true;
             nx_valid = false;
+            if (COUNT) c_path_rays = 0;
             if (NEE) { shadow = false; prev_pdf_b = -1.0f; }
         }
         }  // some lane has no path

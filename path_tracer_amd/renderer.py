@@ -171,6 +171,12 @@ class Renderer:
         check(self._L.pt_counters(self._ctx, C.byref(c)))
         return c
 
+    def path_length_histogram(self) -> np.ndarray:
+        """Samples by the number of path rays they traced (pt_path_length_histogram): 64 bins, the last one open."""
+        out = np.zeros(64, np.uint64)
+        check(self._L.pt_path_length_histogram(self._ctx, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def reset_counters(self):
         check(self._L.pt_reset_counters(self._ctx))
 
@@ -204,5 +210,19 @@ def algorithmic_flops(cnt: dict, ns: int, np_: int, nt: int, pixel_launches: int
     f += b[abi.MAT_LAMBERTIAN] * T["lambert"] + b[abi.MAT_METAL] * T["metal"]
     f += b[abi.MAT_DIELECTRIC] * T["dielectric"] + b[abi.MAT_GLOSSY] * T["glossy"]
     f += cnt["diffuse_updates"] * T["diffuse_update"] + cnt["nee_samples"] * T["nee"]
+    f += pixel_launches * T["accumulate"]
+    return float(f)
+
+
+# The same table applied to the `direct` integrator (renderRegion, cpu_pathtracer/src/main.cpp:14-53), FP64: a primary ray and,
+# per light sample whose cosine is positive, a shadow ray test every sphere, plane and triangle (Scene::intersect /
+# Scene::isVisible are brute force too); a light sample (Sphere::getRandomPoint + direction + cosine, Scene.h:97-112,
+# ImplicitObject.h:111-125) is priced like the path integrator's light sample, its contribution (colour * cos * 50 / d^2,
+# main.cpp:36-41) like a throughput update.  Sphere roots are not counted (the kernel does not count them): a lower bound.
+def direct_flops(cnt: dict, ns: int, np_: int, nt: int, pixel_launches: int) -> float:
+    T = FLOP_TABLE
+    f = cnt["samples"] * T["camera"]
+    f += cnt["rays"] * (ns * T["sphere"] + np_ * T["plane"] + nt * T["triangle"])
+    f += cnt["hits"] * T["hit_record"] + cnt["nee_samples"] * T["nee"] + cnt["shadow_rays"] * T["diffuse_update"]
     f += pixel_launches * T["accumulate"]
     return float(f)

@@ -32,10 +32,12 @@ class Oracle:
         lib.pto_draw.restype = C.c_uint32
         lib.pto_draw.argtypes = [C.c_uint32] * 3
         lib.pto_primary_ids.argtypes = [S, K, _PU, _PU]
+        lib.pto_primary_ids_rect.argtypes = [S, K, C.c_uint32, _PD, _PU, _PU, _PU, _PU]
         lib.pto_render_direct.argtypes = [S, K, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, _PF]
         lib.pto_direct_components.argtypes = [S, K, C.c_uint32, C.c_uint32, C.c_uint32, P, _PD]
         lib.pto_render_path.argtypes = [S, K, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_int, _PF,
                                         C.POINTER(abi.PtCounters)]
+        lib.pto_path_length_histogram.argtypes = [S, K, C.c_uint32, C.c_uint32, P, C.c_int, C.POINTER(C.c_uint64)]
         lib.pto_path_sample.argtypes = [S, K, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_int, _PD]
         lib.pto_path_stats.argtypes = [S, K, C.c_uint32, C.c_uint32, P, _PD, _PD]
         lib.pto_resolve.argtypes = [_PF, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -50,6 +52,19 @@ class Oracle:
         obj, mat = np.empty(n, np.uint32), np.empty(n, np.uint32)
         s = scene.struct()
         self._ck(self.lib.pto_primary_ids(C.byref(s), C.byref(cam), obj.ctypes.data_as(_PU), mat.ctypes.data_as(_PU)))
+        return obj.reshape(cam.height, cam.width), mat.reshape(cam.height, cam.width)
+
+    def primary_ids_rect(self, scene: abi.SceneArrays, cam: abi.PtCamera, rects):
+        """Primary ids with the rectangles [(origin, u, v, obj id, material id), ...] tested by the reference's
+        Rectangle::intersect instead of through their two triangles (which are skipped)."""
+        n = cam.width * cam.height
+        obj, mat = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        ouv = np.ascontiguousarray([list(o) + list(u) + list(v) for o, u, v, _, _ in rects], np.float64).reshape(-1)
+        ro = np.ascontiguousarray([r[3] for r in rects], np.uint32)
+        rm = np.ascontiguousarray([r[4] for r in rects], np.uint32)
+        s = scene.struct()
+        self._ck(self.lib.pto_primary_ids_rect(C.byref(s), C.byref(cam), len(rects), ouv.ctypes.data_as(_PD), ro.ctypes.data_as(_PU),
+                                               rm.ctypes.data_as(_PU), obj.ctypes.data_as(_PU), mat.ctypes.data_as(_PU)))
         return obj.reshape(cam.height, cam.width), mat.reshape(cam.height, cam.width)
 
     def render_direct(self, scene, cam, s0, n, params, accum=None, rows=None):
@@ -77,6 +92,14 @@ class Oracle:
         self._ck(self.lib.pto_render_path(C.byref(s), C.byref(cam), y0, y1, s0, n, C.byref(params), precision,
                                           accum.ctypes.data_as(_PF), C.byref(cnt) if counters else None))
         return (accum, cnt) if counters else accum
+
+    def path_length_histogram(self, scene, cam, s0, n, params, precision=32):
+        """Samples by the number of path rays they traced: 64 bins, the last one open."""
+        out = np.zeros(64, np.uint64)
+        s = scene.struct()
+        self._ck(self.lib.pto_path_length_histogram(C.byref(s), C.byref(cam), s0, n, C.byref(params), precision,
+                                                    out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
 
     def path_sample(self, scene, cam, x, y, smp, params, precision=64):
         out = np.zeros(3, np.float64)

@@ -231,3 +231,50 @@ def test_serial_fallback_when_the_chain_buffers_cannot_be_allocated(monkeypatch)
         finally:
             r.close()
     monkeypatch.delenv("PT_AMD_FAIL_CHAIN_ALLOC")
+
+
+def test_path_length_histogram_matches_oracle(gpu, oracle):
+    """pt_path_length_histogram (the bounce histogram of SURVEY §8(d).4): samples by the number of rays their path
+    traced, against the oracle's on the same samples, and consistent with the event counters."""
+    for name, depth, flags in (("cuda_default", 50, 0), ("glass_stress", 32, 0), ("cuda_default", 50, abi.FLAG_NEE_MIS)):
+        sc, cam = scenes.builtin(name, 160, 90)
+        p = abi.render_params(max_depth=depth, flags=flags | abi.FLAG_COUNTERS)
+        _setup(gpu, sc, cam)
+        gpu.reset_counters()
+        gpu.render(0, 2, p)
+        gpu.render(2, 1, p)
+        hist = gpu.path_length_histogram().astype(np.int64)
+        c = gpu.counters().as_dict()
+        assert hist.sum() == c["samples"] == 160 * 90 * 3
+        assert (hist * np.arange(64)).sum() == c["rays"] - c["shadow_rays"]
+        assert hist[0] == 0 and not hist[depth + 1:].any()
+        want = oracle.path_length_histogram(sc, cam, 0, 3, p).astype(np.int64)
+        # a path in a few thousand branches differently under FP32 rounding (FMA contraction on the GPU): it moves from one
+        # bin to another
+        moved = np.abs(hist - want).sum() / 2
+        assert moved <= 0.003 * hist.sum() + 8, (name, flags, moved)
+        gpu.reset_counters()
+        assert not gpu.path_length_histogram().any()
+
+
+def test_direct_integrator_counters(gpu):
+    """The instrumented build of the FP64 `direct` kernel (PT_FLAG_COUNTERS): samples exact, one primary ray per sample
+    plus one shadow ray per light sample with a positive cosine, one light sample per light for every hit that is not the
+    light itself -- and the same image as the plain build."""
+    sc, cam = scenes.cpu_default(320, 180)
+    p = abi.render_params(integrator=abi.INTEGRATOR_DIRECT)
+    _setup(gpu, sc, cam)
+    gpu.render(0, 4, p)
+    plain = gpu.accum()
+    _setup(gpu, sc, cam)
+    gpu.reset_counters()
+    gpu.render(0, 4, abi.render_params(integrator=abi.INTEGRATOR_DIRECT, flags=abi.FLAG_COUNTERS))
+    assert np.array_equal(gpu.accum(), plain)
+    c = gpu.counters().as_dict()
+    n = 320 * 180 * 4
+    assert c["samples"] == n and c["hits"] == n                  # cpu_default's camera sees no background (SURVEY D5)
+    assert c["rays"] == n + c["shadow_rays"]
+    assert 0 < c["shadow_rays"] <= c["nee_samples"] <= n          # one light: at most one light sample per sample
+    ids, _ = gpu.primary_ids()
+    light_share = float((ids == 7).mean())                       # the emissive sphere is object 7
+    assert abs(c["nee_samples"] / n - (1.0 - light_share)) < 0.01

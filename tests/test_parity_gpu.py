@@ -182,9 +182,11 @@ PATH_MEAN_LIMIT = {("cuda_default", 0): 0.0016,   # 0.00051
 # epsilon (1e-4, Ray.cuh:38) and of its origin offsets (1e-3; none for Glossy, Material.cuh:204).  Whether a scattered
 # ray re-hits the sphere it leaves is then decided by rounding, which FMA contraction (hipcc, as nvcc's default for the
 # reference) and the oracle's uncontracted arithmetic round differently: ~25x more paths branch than in the Cornell box.
-RANDOM4096_FRAC_LIMIT = {0: 0.030, _N: 0.15, _M: 0.15}        # measured 0.0106, 0.0635, 0.0635
-RANDOM4096_MEAN_LIMIT = {0: 0.011, _N: 0.02, _M: 0.02}         # measured 0.0036
-RANDOM4096_COUNTER_LIMIT = 0.05                                # measured <= 0.0186 (sphere_roots; glossy chains)
+# That claim is MEASURED in the test: the float and the double build of the oracle (same formulas, same RNG, only the
+# rounding differs) disagree on a share of the pixels and of the events; the GPU may differ from the float oracle by at
+# most 1.5 x that share plus a small absolute allowance, and its event counts must lie within the band the two oracle
+# builds span, widened by the same factor.  (Round 2 used constants here: 0.030 / 0.15 / 0.15.)
+RANDOM4096_MEAN_LIMIT = {0: 0.011, _N: 0.02, _M: 0.02}         # measured 0.0036 (the mean is a sum over branched paths: no rounding baseline)
 
 
 @pytest.mark.parametrize("name,flags,depth", [
@@ -228,27 +230,45 @@ def test_path_random_spheres_matches_float_oracle(gpu, oracle, flags):
     gpu.render(0, 4, p)
     got = gpu.accum()
     want, oc = oracle.render_path(sc, cam, 0, 4, p, precision=32, counters=True)
+    w64, oc64 = oracle.render_path(sc, cam, 0, 4, p, precision=64, counters=True)
     assert np.all(got[..., 3] == 4) and np.isfinite(got).all()
     tag = f"path_random4096_flags{flags}_96x54_4spp"
-    _bound(tag + "/frac_pixels_differing", _frac_differing(_mean(got), _mean(want)), RANDOM4096_FRAC_LIMIT[flags])
+    gm, wm, dm = _mean(got), _mean(want), _mean(w64)
+    # the rounding baseline: float oracle against double oracle, at both tolerances
+    base_1e3, base_2pc = _frac_differing(wm, dm), _frac_differing(wm, dm, tol=2e-2)
+    _MEASURED[tag + "/rounding_baseline_frac_1e-3"] = {"measured": base_1e3, "limit": None, "kind": "baseline"}
+    _MEASURED[tag + "/rounding_baseline_frac_2pct"] = {"measured": base_2pc, "limit": None, "kind": "baseline"}
+    _bound(tag + "/frac_pixels_differing", _frac_differing(gm, wm), 1.5 * base_1e3 + 0.01)
     # ... most of which is numerical jitter, not a path that branched: a sphere of radius 0.3 seen from 50 units away
     # has normals good to 1e-5 (p - c cancels six digits), so a grazing light sample's cosine differs by a fraction
     # of a per cent between two correctly rounded evaluations.  At a 2 % tolerance only the branched paths remain.
-    _bound(tag + "/frac_pixels_differing_beyond_2pct", _frac_differing(_mean(got), _mean(want), tol=2e-2), 0.03)
-    _bound(tag + "/rel_mean_diff", abs(_mean(got).mean() - _mean(want).mean()) / _mean(want).mean(), RANDOM4096_MEAN_LIMIT[flags])
-    g, o = gpu.counters().as_dict(), oc.as_dict()
-    assert g["samples"] == o["samples"] == 96 * 54 * 4
+    _bound(tag + "/frac_pixels_differing_beyond_2pct", _frac_differing(gm, wm, tol=2e-2), 1.5 * base_2pc + 0.005)
+    # the GPU is as close to the double referee as the float oracle is
+    _bound(tag + "/frac_pixels_differing_from_double", _frac_differing(gm, dm), 1.5 * base_1e3 + 0.01)
+    _bound(tag + "/rel_mean_diff", abs(gm.mean() - wm.mean()) / wm.mean(), RANDOM4096_MEAN_LIMIT[flags])
+    g, o, o64 = gpu.counters().as_dict(), oc.as_dict(), oc64.as_dict()
+    assert g["samples"] == o["samples"] == o64["samples"] == 96 * 54 * 4
     for k in ("rays", "hits", "sphere_roots", "diffuse_updates", "nee_samples", "shadow_rays"):
-        _bound(f"{tag}/counter_{k}_rel_diff", abs(g[k] - o[k]) / max(o[k], 1), RANDOM4096_COUNTER_LIMIT)
+        # between the two oracle builds, or outside by no more than half their distance plus counting noise
+        lo, hi = min(o[k], o64[k]), max(o[k], o64[k])
+        slack = 0.5 * (hi - lo) + 4.0 * np.sqrt(max(hi, 1)) + 0.002 * hi
+        _MEASURED[f"{tag}/counter_{k}"] = {"measured": g[k], "limit": [lo - slack, hi + slack], "kind": "band", "float_oracle": o[k], "double_oracle": o64[k]}
+        assert lo - slack <= g[k] <= hi + slack, (k, g[k], o[k], o64[k])
     if flags & abi.FLAG_NEE_MIS:
         assert g["nee_samples"] > 0 and g["shadow_rays"] > 0
 
 
-def test_path_three_sigma_and_rmse(gpu, oracle):
-    """north_star's tolerance, at a resolution the double-precision oracle finishes in seconds:
-    per-pixel mean within 3 sigma of the estimator (sigma from the oracle's own per-sample
-    variance), and global RMSE of the displayed ([0,1]-clamped) image below 1e-3 x sqrt(4096/N)."""
-    W, H, N = 64, 36, 4096
+@pytest.mark.parametrize("size", [(64, 36), (160, 90)])
+def test_path_three_sigma_and_rmse(gpu, oracle, size):
+    """north_star's tolerance, at two resolutions the double-precision oracle finishes in seconds (2 304 and 14 400
+    pixels; 9.4 M and 59 M samples): per-pixel mean within 3 sigma of the estimator (sigma from the oracle's own
+    per-sample variance), and global RMSE of the displayed ([0,1]-clamped) image below 1e-3 at 4096 spp.  GPU and
+    oracle trace the same sample set, so the RMSE is not Monte-Carlo noise: it is the few paths per thousand that
+    branch differently under FP32 rounding, each moving one pixel by (its radiance) / 4096.  The share of such pixels
+    and the RMSE without them are recorded too: the margin to 1e-3 is a property of the scene's brightest paths
+    (light hits are 15.0 before the clamp), not of the resolution."""
+    W, H = size
+    N = 4096
     sc, cam = scenes.cuda_default(W, H)
     p = abi.render_params()
     _setup(gpu, sc, cam)
@@ -257,11 +277,31 @@ def test_path_three_sigma_and_rmse(gpu, oracle):
     gm = _mean(gpu.accum()).astype(np.float64)
     mean, var = oracle.path_stats(sc, cam, 0, N, p)
     sigma = np.sqrt(var / N)
-    # same sample set on both sides: the difference is far inside the estimator's own 3 sigma
+    tag = f"three_sigma_{W}x{H}_4096spp"
+    # The rounding baseline: the FLOAT build of the oracle (the reference's arithmetic, uncontracted) against the same
+    # double referee.  Both float implementations differ from the referee by the paths that branch under FP32 rounding;
+    # what the tolerance can ask of the GPU is to be no further away than correctly rounded float arithmetic is.
+    fm = _mean(oracle.render_path(sc, cam, 0, N, p, precision=32)).astype(np.float64)
+    base_inside = float((np.abs(fm - mean) <= 3.0 * sigma + 1e-4).mean())
+    base_rmse = float(np.sqrt(((np.clip(fm, 0, 1) - np.clip(mean, 0, 1)) ** 2).mean()))
+    _MEASURED[tag + "/float_oracle_frac_inside"] = {"measured": base_inside, "limit": None, "kind": "baseline"}
+    _MEASURED[tag + "/float_oracle_rmse_clamped"] = {"measured": base_rmse, "limit": None, "kind": "baseline"}
+    # same sample set on both sides: the difference is far inside the estimator's own 3 sigma (the pixels outside are
+    # those whose estimator has no variance to speak of -- a light seen directly is 15.0 in every sample -- and one
+    # branched path among 4096)
     inside = np.abs(gm - mean) <= 3.0 * sigma + 1e-4
-    _bound("three_sigma_64x36_4096spp/frac_inside", inside.mean(), 0.999, at_least=True)
-    rmse = float(np.sqrt(((np.clip(gm, 0, 1) - np.clip(mean, 0, 1)) ** 2).mean()))
-    _bound("three_sigma_64x36_4096spp/rmse_clamped", rmse, 1e-3 * np.sqrt(4096.0 / N))   # north_star: RMSE < 1e-3 at 4096 spp
+    _bound(tag + "/frac_inside", inside.mean(), min(0.999, base_inside - 0.001), at_least=True)
+    diff = np.clip(gm, 0, 1) - np.clip(mean, 0, 1)
+    rmse = float(np.sqrt((diff ** 2).mean()))
+    _bound(tag + "/rmse_clamped", rmse, 1e-3 * np.sqrt(4096.0 / N))   # north_star: RMSE < 1e-3 at 4096 spp
+    _bound(tag + "/rmse_clamped_over_float_oracle_baseline", rmse / base_rmse, 1.3)
+    # where the RMSE comes from: pixels that differ by more than float summation noise hold a path that branched
+    branched = np.abs(diff).max(axis=2) > 2e-5
+    _MEASURED[tag + "/frac_pixels_with_a_branched_path"] = {"measured": float(branched.mean()), "limit": None, "kind": "info"}
+    _MEASURED[tag + "/rmse_clamped_without_them"] = {"measured": float(np.sqrt((diff[~branched] ** 2).mean())), "limit": None, "kind": "info"}
+    _bound(tag + "/rmse_clamped_without_branched_pixels", float(np.sqrt((diff[~branched] ** 2).mean())), 2e-5)
+    # and in relative terms (unclamped means): the image means agree to a few parts in 10^5
+    _bound(tag + "/rel_mean_diff", abs(gm.mean() - mean.mean()) / mean.mean(), 2.5e-5)   # measured 3.4e-6 / 8.1e-6
 
 
 def test_mis_on_equals_mis_off_in_expectation(gpu):
@@ -868,28 +908,21 @@ def test_scripted_camera_resets_accumulation_on_movement(gpu, oracle):
 
 
 # ------------------------------------------------- composite objects (§8f.4) on the GPU ---
-def _composite_scene(w, h):
-    from path_tracer_amd.scenes import Emissive, Lambertian, Metal, SceneBuilder
-    b = SceneBuilder()
-    white, red, mirror = b.material(Lambertian(0.73)), b.material(Lambertian((0.65, 0.05, 0.05))), b.material(Metal((0.9, 0.9, 0.9), 0.0))
-    lamp = b.material(Emissive((1.0, 0.9, 0.8), 15.0))
-    b.addObject(b.Plane((0, -2, 0), (0, 1, 0), white))
-    b.addObject(b.Plane((0, 0, -3), (0, 0, 1), white))
-    b.addObject(b.Rectangle((-1.0, 1.9, -2.0), (2.0, 0, 0), (0, 0, 1.5), lamp))      # area light facing down
-    b.addObject(b.Rectangle((-2.0, -2.0, -2.5), (0, 0, 2.0), (0, 2.5, 0), red))      # a red panel
-    b.addObject(b.Tetrahedron([(0.0, 0.2, -1.2), (-0.7, -1.0, -0.6), (0.7, -1.0, -0.6), (0.0, -1.0, -1.9)], mirror))
-    b.addObject(b.Sphere((1.2, -1.4, -1.0), 0.6, white))
-    cam = abi.make_camera((0, 0, 1.6), (0, -0.3, -1), (0, 1, 0), 70.0, w, h, abi.CAMERA_CUDA)
-    return b.flatten(), cam
+from tests.composite_scene import composite_scene as _composite_scene, rectangle_ids_agree
 
 
 def test_composite_objects_ids_and_path(gpu, oracle):
-    sc, cam = _composite_scene(200, 120)
+    sc, cam, rects = _composite_scene(200, 120)
     _setup(gpu, sc, cam)
     ids, mats = gpu.primary_ids()
     oid, omat = oracle.primary_ids(sc, cam)
     assert np.array_equal(ids, oid) and np.array_equal(mats, omat)
     assert {2, 3, 4} <= set(np.unique(ids).tolist())          # both rectangles and the tetrahedron are visible
+    # the rectangles as the REFERENCE tests them (Rectangle_t::intersect, Polygon.cuh:130-168: alpha, beta in [0, 1]),
+    # against the HIP id pass on the two triangles the host flattens each to
+    rid, rmat = oracle.primary_ids_rect(sc, cam, rects)
+    differing = rectangle_ids_agree(ids, mats, rid, rmat, [r[3] for r in rects])
+    _bound("composite_200x120/pixels_where_rectangle_formula_and_triangles_differ", differing, 3)   # measured 0 (of 24 000)
     p = abi.render_params(max_depth=12)
     gpu.render(0, 16, p)
     got = gpu.accum()
@@ -1455,3 +1488,10 @@ def test_bench_line_contract():
     assert abs(l["value"] - 3840 * 2160 * 1024 / (l["wall_ms"] * 1e-3) / 1e6) < 0.01 * l["value"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == d["unit"]
+    # the FP64 `direct` leg (BASELINE config 1: cpu_default, 1280x720, 64 spp per step), with the oracle's renderRegion beside it
+    g = d["legs"]["cpu_default_direct_720p_64spp"]
+    assert g["baseline_config"] == 1 and g["dtype"] == "f64" and g["spp_per_step"] == 64 and g["value"] > 0
+    assert g["roofline"]["bound"] == "valu_fp64" and 0 < g["roofline"]["frac"] < 1
+    assert abs(g["value"] - 1280 * 720 * 64 / (g["ms_per_step"] * 1e-3) / 1e6) < 0.01 * g["value"]
+    assert 1.0 <= g["rays_per_sample"] <= 2.0      # a primary ray and at most one shadow ray (one light)
+    assert g["cpu_baseline"]["kind"] == "port" and g["cpu_baseline"]["value"] > 0

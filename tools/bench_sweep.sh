@@ -3,7 +3,7 @@ set -e
 run() { # label, bench flags, env...
   label=$1; shift; flags=$1; shift
   for steps in "20 5" "1024 32" "1024 32"; do
-    env "$@" timeout -k 10 120 python bench.py --gpus 1 --steps ${steps% *} --warmup ${steps#* } --cpu-seconds 0 --no-4k-leg $flags > gpurun_out/sweep_tmp.json 2>gpurun_out/sweep_err.txt || { tail -5 gpurun_out/sweep_err.txt; exit 1; }
+    env "$@" timeout -k 10 120 python bench.py --gpus 1 --steps ${steps% *} --warmup ${steps#* } --cpu-seconds 0 --no-4k-leg --no-direct-leg $flags > gpurun_out/sweep_tmp.json 2>gpurun_out/sweep_err.txt || { tail -5 gpurun_out/sweep_err.txt; exit 1; }
     python -c "
 import json
 d=json.loads(open('gpurun_out/sweep_tmp.json').read().strip().splitlines()[-1])

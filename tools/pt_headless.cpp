@@ -19,6 +19,7 @@ static void usage() {
         "                   [--spp N] [--spp-per-launch K] [--max-depth D] [--integrator path|direct] [--seed S]\n"
         "                   [--mis] [--light-colour] [--device I] [--resume raw] [--out image.ppm] [--raw accum.f32]\n"
         "                   [--frames-in-flight 1..8]  overlap consecutive launches (progressive rendering at few spp per launch)\n"
+        "                   [--counters]  run the instrumented kernel: print the event counters and the path-length histogram\n"
         "                   [--script camera.txt]   lines: <frames> <mouse_dx> <mouse_dy> <keys: wasd u(p) c(down) or ->\n"
         "                                           (the CPU app's frame loop, main.cpp:153-237, 1 spp per frame;\n"
         "                                           --out then names a printf pattern, one PPM per script line)");
@@ -28,6 +29,7 @@ int main(int argc, char** argv) {
     std::string scene = "cuda_default", integrator, out, raw, resume, script;
     uint32_t W = 1280, H = 720, spp = 64, per = 0, depth = 0, seed = 0x5EED0001u, flags = 0, flight = 1;
     int device = 0;
+    bool counters = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { usage(); std::exit(2); } return argv[++i]; };
@@ -47,6 +49,7 @@ int main(int argc, char** argv) {
         else if (a == "--resume") resume = next();
         else if (a == "--script") script = next();
         else if (a == "--frames-in-flight") flight = (uint32_t)std::atoi(next());
+        else if (a == "--counters") counters = true;
         else { usage(); return a == "--help" ? 0 : 2; }
     }
     try {
@@ -55,7 +58,7 @@ int main(int argc, char** argv) {
         if (integrator.empty()) integrator = scene == "cpu_default" ? "direct" : "path";
         PtRenderParams p = pt::defaultParams();
         p.integrator = integrator == "direct" ? PT_INTEGRATOR_DIRECT : PT_INTEGRATOR_PATH;
-        p.seed = seed; p.flags = flags;
+        p.seed = seed; p.flags = flags | (counters ? PT_FLAG_COUNTERS : 0u);
         p.max_depth = depth ? depth : (scene == "glass_stress" ? 32u : scene == "random4096" ? 16u : 50u);
         if (p.integrator == PT_INTEGRATOR_PATH) c.model = PT_CAMERA_CUDA;
         if (per == 0) per = spp < 16 ? spp : 16;
@@ -137,6 +140,18 @@ int main(int argc, char** argv) {
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::printf("{\"scene\": \"%s\", \"integrator\": \"%s\", \"width\": %u, \"height\": %u, \"spp\": %u, \"seconds\": %.6f, "
                     "\"msamples_per_s\": %.3f}\n", scene.c_str(), integrator.c_str(), W, H, spp, sec, npix * (double)spp / sec / 1e6);
+        if (counters) {   // the event counters that feed the FLOP model and the bounce histogram (§8(d).4)
+            PtCounters k; uint64_t h[PT_HISTOGRAM_BINS];
+            pt::check(pt_counters(r.ctx(), &k));
+            pt::check(pt_path_length_histogram(r.ctx(), h));
+            std::printf("{\"counters\": {\"samples\": %llu, \"rays\": %llu, \"hits\": %llu, \"sphere_roots\": %llu, \"bounces\": [%llu, %llu, %llu, %llu, %llu], "
+                        "\"diffuse_updates\": %llu, \"nee_samples\": %llu, \"shadow_rays\": %llu}, \"path_length_histogram\": [",
+                        (unsigned long long)k.samples, (unsigned long long)k.rays, (unsigned long long)k.hits, (unsigned long long)k.sphere_roots,
+                        (unsigned long long)k.bounces[0], (unsigned long long)k.bounces[1], (unsigned long long)k.bounces[2], (unsigned long long)k.bounces[3],
+                        (unsigned long long)k.bounces[4], (unsigned long long)k.diffuse_updates, (unsigned long long)k.nee_samples, (unsigned long long)k.shadow_rays);
+            for (uint32_t b = 0; b < PT_HISTOGRAM_BINS; ++b) std::printf("%s%llu", b ? ", " : "", (unsigned long long)h[b]);
+            std::printf("]}\n");
+        }
         if (!out.empty()) {
             r.resolve(PT_RESOLVE_RGB8_PPM);
             std::vector<unsigned char> img(npix * 3);
