@@ -9,11 +9,13 @@ into one launch of the path kernel (up to 64; include/pt.h) and folds them into 
 making every frame's RGBA8 display on the way: same sums and same pictures as one launch per frame, bit for bit.
   N = 1 : K frames on one GPU.
   N > 1 : sample-split, weak scaling — every rank renders K frames of 1 spp for its own
-          disjoint sample indices, then the float4 accumulation buffers are summed once with an
-          RCCL reduce to rank 0 (inside the timed region, also reported on its own as `reduce_ms`),
-          which resolves the image.
+          disjoint sample indices, then the float4 accumulation buffers are combined once with an
+          RCCL reduce-scatter (every rank receives and adds the sums of 1/N of the pixels), each rank
+          resolves its own slice and the 4-byte pixels are all-gathered (inside the timed region;
+          `reduce_ms` and `display_ms` report the two parts from HIP events, no host synchronisation
+          between the render and the closing barrier).
 BASELINE's metric is quoted "at 1280x720 & 4K", and north_star's scaling target is defined on
-config 3 (4K at 1024 spp, sample-split with one RCCL reduce), so every run also carries that
+config 3 (4K at 1024 spp, sample-split with one RCCL sum-reduce), so every run also carries that
 workload as a second leg under `legs`: 3840x2160, 16 spp per step, 64 steps = 1024 spp, the steps
 DIVIDED among the ranks (strong scaling), wall time including the reduce.  At N = 1 it is the
 single-GPU 4K figure the N > 1 runs compare with.  (`--no-4k-leg` leaves it out.)
@@ -51,6 +53,9 @@ WORKLOADS = {
     "cornell_4k_16spp_per_step": ("cuda_default", 3840, 2160, 16, 50),
     "glass_stress_720p_16spp_per_step": ("glass_stress", 1280, 720, 16, 32),
     "random4096_4k_1spp_per_step": ("random4096", 3840, 2160, 1, 16),
+    # the scene sizes between the Cornell box and config 5 that the launch heuristics are swept on (tools/bench_sweep.sh)
+    "spheres150_720p_1spp_per_step": ("random149", 1280, 720, 1, 16),
+    "spheres1000_360p_1spp_per_step": ("random999", 640, 360, 1, 16),
 }
 LEG_4K = ("cornell_4k_16spp_per_step", 64, 2)  # BASELINE config 3: 64 steps of 16 spp = 1024 spp; 2 warm-up steps
 
@@ -86,7 +91,7 @@ def main() -> int:
     import torch.distributed as dist
 
     from path_tracer_amd import abi, scenes
-    from path_tracer_amd.distributed import progressive_schedule, reduce_accum, strong_schedule
+    from path_tracer_amd.distributed import gather_display, pixel_slice, progressive_schedule, reduce_scatter_accum, strong_schedule
     from path_tracer_amd.renderer import Renderer, algorithmic_flops
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,8 +164,13 @@ def main() -> int:
         for s0, n in sched[:Wm]:
             r.render(s0, n, params)
         r.flush()
-        if world > 1:  # warm the collective too
-            reduce_accum(accum.clone())
+        npix = W * H
+        chunk = -(-npix // world)
+        my_first, my_count = pixel_slice(npix, world, rank)
+        disp_slice = torch.zeros(chunk, device="cuda", dtype=torch.int32) if world > 1 else None
+        if world > 1:  # warm the collectives too (on a copy: the buffer keeps its samples)
+            reduce_scatter_accum(accum.clone())
+            gather_display(disp_slice, npix)
         barrier()
         stage(f"{workload}: timed region starts")
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -172,26 +182,37 @@ def main() -> int:
         r.flush()  # frames in flight: launches what is held back; the launch stream waits for the last fold pass (asynchronous)
         ev1.record()
         launches = max(r.path_launches() - launches0, 1)
-        t_render = t_reduce = None
+        ev2 = ev3 = None
+        picture = None
         if world > 1:
-            torch.cuda.synchronize()
-            t_render = time.perf_counter()
-            reduce_accum(accum, dst=0)
-            torch.cuda.synchronize()
-            t_reduce = time.perf_counter()
-        if rank == 0:
+            # Combine: reduce-scatter of the float4 buffers (every rank receives and adds the sums of 1/N of the
+            # pixels), each rank resolves its own slice, the 4-byte pixels are gathered.  Everything is enqueued on this
+            # stream -- torch's collectives make the current stream wait, the library's resolve runs on it -- and timed with
+            # events: no host synchronisation between the render and the barrier that ends the timed region.
+            ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            first, count = reduce_scatter_accum(accum)
+            ev2.record()
+            if count:
+                r.resolve_range(abi.RESOLVE_RGBA8_CUDA, first, count, disp_slice)
+            picture = gather_display(disp_slice, npix)
+            ev3.record()
+        else:
             r.resolve(abi.RESOLVE_RGBA8_CUDA)
         barrier()
         t_end = time.perf_counter()
         elapsed = t_end - t0
         stage(f"{workload}: timed region done")
         total_steps = K if scaling == "strong" else world * K
-        if rank == 0:
-            # every pixel now holds the samples of every rank (warm-up steps included), each once
-            want_w = float((world * Wm + total_steps) * spp)
-            w_min, w_max = float(accum[..., 3].min()), float(accum[..., 3].max())
+        # every pixel of this rank's slice (the whole frame at N = 1) now holds the samples of every rank (warm-up steps
+        # included), each once: the count channel is known analytically and checked, not trusted
+        want_w = float((world * Wm + total_steps) * spp)
+        if my_count:
+            mine = accum.view(-1, 4)[my_first:my_first + my_count, 3]
+            w_min, w_max = float(mine.min()), float(mine.max())
             if w_min != want_w or w_max != want_w:
-                raise RuntimeError(f"{workload}: accumulation buffer holds {w_min}..{w_max} samples per pixel, expected {want_w}")
+                raise RuntimeError(f"{workload}: rank {rank}'s pixels hold {w_min}..{w_max} samples, expected {want_w}")
+        if picture is not None and rank == 0 and int((picture != 0).sum()) == 0:
+            raise RuntimeError(f"{workload}: the gathered picture is empty")
         my_steps = len(sched) - Wm
         # HIP events on the launch stream around this rank's frames (the chains fork from and join this stream): first
         # launch start to last fold pass end, per frame -- the path kernel with its launches overlapping, plus the fold
@@ -210,17 +231,21 @@ def main() -> int:
             ev3.record()
             torch.cuda.synchronize()
             serial_ms = ev2.elapsed_time(ev3) / n_serial
-        render_s = (t_render - t0) if t_render else elapsed
-        reduce_s = (t_reduce - t_render) if t_reduce else 0.0
+        # the parts of the timed region, from the events (device time on this rank's stream): render = first launch to last
+        # fold pass; reduce = the reduce-scatter behind it; display = this rank's resolve + the all-gather of the pictures
+        render_s = ev0.elapsed_time(ev1) * 1e-3 if world > 1 else elapsed
+        reduce_s = ev1.elapsed_time(ev2) * 1e-3 if world > 1 else 0.0
+        display_s = ev2.elapsed_time(ev3) * 1e-3 if world > 1 else 0.0
         if world > 1:
-            t = torch.tensor([elapsed, frame_ms, render_s, reduce_s], device="cuda", dtype=torch.float64)
+            t = torch.tensor([elapsed, frame_ms, render_s, reduce_s, display_s], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed, frame_ms, render_s, reduce_s = (float(v) for v in t)
+            elapsed, frame_ms, render_s, reduce_s, display_s = (float(v) for v in t)
         out = {"workload": workload, "scene": scene_name, "width": W, "height": H, "spp_per_step": spp, "max_depth": max_depth,
                "steps": K, "warmup": Wm, "scaling": scaling if world > 1 else "weak", "frames_in_flight": flight,
                "elapsed_s": elapsed, "total_steps": total_steps, "samples_per_step": W * H * spp,
                "value": total_steps * W * H * spp / elapsed / 1e6, "frame_ms": frame_ms, "launches": launches, "serial_ms": serial_ms,
-               "render_ms": render_s * 1e3, "reduce_ms": reduce_s * 1e3, "my_steps": my_steps}
+               "render_ms": render_s * 1e3, "reduce_ms": reduce_s * 1e3, "display_ms": display_s * 1e3, "my_steps": my_steps,
+               "reduce_bytes": (world - 1) * chunk * 16 if world > 1 else 0, "gather_bytes": (world - 1) * chunk * 4 if world > 1 else 0}
         if rank == 0:
             # ---- algorithmic FLOPs per launch from the instrumented kernel (same samples as timed steps) --
             r.unbind()
@@ -344,14 +369,17 @@ def main() -> int:
                        "spp_per_step": head["spp_per_step"], "max_depth": head["max_depth"], "integrator": "path+nee_mis" if args.mis else "path",
                        "accumulate": "sum+display_rgba8_per_frame", "frames_in_flight": head["frames_in_flight"],
                        "parallelism": f"sample_split{world}" if world > 1 else "single",
-                       "reduce": ("gloo_rehearsal_on_one_gpu" if rehearsal else "rccl_reduce_sum_once") if world > 1 else None},
+                       "reduce": ("gloo_rehearsal_on_one_gpu" if rehearsal else "rccl_reduce_scatter_sum_once+resolve_own_slice+all_gather_rgba8") if world > 1 else None},
             "mrays_per_s": round(head["value"] * head["rays_per_sample"], 1), "rays_per_sample": round(head["rays_per_sample"], 4),
             "roofline": roofline(head, True),
         }
         if world > 1:  # the collective and the rest of the timed region, apart (max over ranks)
             result["render_ms"] = round(head["render_ms"], 4)
             result["reduce_ms"] = round(head["reduce_ms"], 4)
-            result["resolve_and_barrier_ms"] = round(head["elapsed_s"] * 1e3 - head["render_ms"] - head["reduce_ms"], 4)
+            result["display_ms"] = round(head["display_ms"], 4)
+            result["reduce_bytes_per_rank"] = head["reduce_bytes"]
+            result["gather_bytes_per_rank"] = head["gather_bytes"]
+            result["host_and_barrier_ms"] = round(head["elapsed_s"] * 1e3 - head["render_ms"] - head["reduce_ms"] - head["display_ms"], 4)
         if leg4k:
             l = leg4k
             result["legs"] = {"cornell_4k_1024spp_strong_split": {
@@ -359,7 +387,8 @@ def main() -> int:
                 "n_gpus": world, "scaling": "strong", "width": l["width"], "height": l["height"], "spp_total": l["steps"] * l["spp_per_step"],
                 "spp_per_step": l["spp_per_step"], "steps": l["steps"], "steps_per_rank_max": -(-l["steps"] // world), "warmup": l["warmup"],
                 "wall_ms": round(l["elapsed_s"] * 1e3, 3), "render_ms": round(l["render_ms"], 3), "reduce_ms": round(l["reduce_ms"], 3),
-                "reduce_bytes": l["width"] * l["height"] * 16 if world > 1 else 0, "frames_in_flight": l["frames_in_flight"],
+                "display_ms": round(l["display_ms"], 3), "reduce_bytes_per_rank": l["reduce_bytes"], "gather_bytes_per_rank": l["gather_bytes"],
+                "frames_in_flight": l["frames_in_flight"],
                 "roofline": roofline(l, False)}}
         if leg_direct:
             result.setdefault("legs", {})["cpu_default_direct_720p_64spp"] = leg_direct

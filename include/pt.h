@@ -311,6 +311,13 @@ int pt_flush(PtContext* ctx);
 /* Resolve the accumulation buffer into the context's display buffer
  * (convertToRGBAKernel / the CPU accumulate+gamma loop).  Asynchronous. */
 int pt_resolve(PtContext* ctx, uint32_t mode);
+/* The same conversion for pixels [first_pixel, first_pixel + pixel_count) of the accumulation buffer (row-major
+ * pixel index) into a CALLER-OWNED device buffer (pixel_count elements of the mode's size: 4 B, 16 B for
+ * PT_RESOLVE_FLOAT_MEAN, 3 B for PT_RESOLVE_RGB8_PPM).  Multi-GPU hosts that combine their buffers with a
+ * reduce-scatter (each rank then owns the sums of 1/N of the pixels) resolve their own slice with this
+ * and gather the 4-byte pixels, instead of sending every float to one GPU.  The context's display buffer and the
+ * display history are not touched.  No counterpart in the reference (single GPU, main.cu:30).  Asynchronous. */
+int pt_resolve_range(PtContext* ctx, uint32_t mode, uint32_t first_pixel, uint32_t pixel_count, void* dev_out);
 /* Copy the display buffer of the last pt_resolve / fused render to the host
  * (Window_t::updateScreen's cudaMemcpy, Window.cuh:160).  Synchronises. */
 int pt_readback(PtContext* ctx, void* host_dst, size_t bytes);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "pt_readback_accum", "pt_history_frames", "pt_readback_history", "pt_upload_accum", "pt_sync", "pt_accum_device_ptr", "pt_display_device_ptr",
     "pt_primary_ids", "pt_counters", "pt_reset_counters", "pt_valu_peak", "pt_make_current",
     "launchRenderKernel", "pt_builtin_scene", "pt_set_frames_in_flight", "pt_frames_in_flight", "pt_path_launches", "pt_flush",
-    "pt_fly_camera_step", "pt_reduce", "pt_render_noalloc", "pt_path_length_histogram",
+    "pt_fly_camera_step", "pt_reduce", "pt_render_noalloc", "pt_path_length_histogram", "pt_resolve_range",
 ]
 
 _lib = None
@@ -62,6 +62,7 @@ def lib() -> C.CDLL:
     L.pt_render.argtypes = [ctx, u32, u32, C.POINTER(abi.PtRenderParams)]
     L.pt_render_noalloc.argtypes = [ctx, vp, u32, u32, u32, u32, C.POINTER(abi.PtRenderParams)]
     L.pt_resolve.argtypes = [ctx, u32]
+    L.pt_resolve_range.argtypes = [ctx, u32, u32, u32, vp]
     L.pt_readback.argtypes = [ctx, vp, C.c_size_t]
     L.pt_readback_accum.argtypes = [ctx, vp, C.c_size_t]
     L.pt_path_launches.argtypes = [ctx]

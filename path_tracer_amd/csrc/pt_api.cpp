@@ -420,6 +420,51 @@ int render_in_parts(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count
     return rc;
 }
 
+// ---- Launch tuning table ------------------------------------------------------------------------------------------
+// Every fitted constant of launch_now() in one place, with the measurement it came from.  The sweeps are reproducible:
+// tools/heuristics_sweep.py (few_max, regen_min, idle_min, grid, prefetch on scenes of 19 / 150 / 1 000 / 4 097
+// primitives, serial and in flight; profiles/r2_heuristics_sweep.json, profiles/r3_heuristics_sweep.json),
+// tools/chunk_sweep.py (samples per frame of a large call), tools/bench_sweep.sh (chains, frames per launch; it also runs
+// the 150- and 1 000-primitive scenes, so a kernel change that moves an optimum shows as a number).  The guard
+// tests/test_y_heuristics_gpu.py fails when a default falls 20 % behind the best setting of a small sweep (round 3,
+// medians: every default within 4 % of the best at all four scene sizes).
+namespace tune {
+// Cost of one pass of the 64-ray intersection loop, in VALU instructions per primitive (static counts of `make isa`,
+// tools/isa_sections.py: a sphere 11 + 12 for the root block, an axis plane 6, a general plane 13, a triangle 26-35 with
+// its share of the batch overhead).  Only ratios matter: the sum is compared with the lane-parallel form's cost per ray.
+constexpr uint32_t COST_SPHERE = 25, COST_AXIS_PLANE = 7, COST_PLANE = 13, COST_TRIANGLE = 35;
+// Cost per ray of the lane-parallel closest hit: broadcast + reduction, one test per 64 primitives of a kind, and the
+// unhidden wait for every 64 primitives that come from global memory instead of LDS (the first two such waits cost more
+// than the later ones, which overlap).  Fitted on the few_max sweep: best threshold 3 / 14 / 28 / 30 rays at 19 / 150 /
+// 1 000 / 4 097 primitives; a model without the waits gave 3 / 27 / 48 / 48 and lost 25 % at 150 primitives.
+constexpr uint32_t FEW_BASE = 40, FEW_PER_64_SPHERES = 27, FEW_PER_64_PLANES = 15, FEW_PER_64_TRIANGLES = 37;
+constexpr uint32_t FEW_GLOBAL_WAIT_FIRST = 60, FEW_GLOBAL_WAIT_NEXT = 25;
+constexpr uint32_t FEW_MAX_CAP = 32;            // beyond half a wave the 64-ray loop always wins
+// The build with the lane-parallel mode costs the common loop 3-4 %: it is left out of launches that overlap others or
+// give every lane >= 100 samples (4K / 16 spp: -3 % with it) unless the scene is large enough for a threshold of >= 6 rays
+// (serial 720p / 1 spp: +15 % with it; 150+ primitives: +30...70 % everywhere).
+constexpr uint32_t FEW_LONG_LAUNCH_SAMPLES_PER_LANE = 100, FEW_MIN_THRESHOLD_WHEN_OVERLAPPED = 6;
+constexpr uint32_t LANES_PER_CU_AT_6_WAVES = 6u * 256u;
+// Grid of overlapped launches.  The chains' grids together are ~1.35x the resident capacity (27 / 20 of it, divided among
+// the chains); a launch with >= 14 samples per lane gets as many waves as that allows; a sample of a large scene counts as
+// serial_cost / 400 Cornell samples (random4096 at 720p: 8 x 259 blocks 168 Msamples/s, 4 x 518 226).  Measured at 720p /
+// 1 spp, Gsamples/s: 4 x 518 blocks 8.5, 6 x 345 9.3, 8 x 259 9.5, 8 x 514 8.6; 4K / 16 spp: 8 x 1536 11.0, 8 x 400 8.6.
+constexpr uint32_t GRID_FILL_NUM = 27, GRID_FILL_DEN = 20, GRID_SAMPLES_PER_LANE = 14, GRID_COST_OF_A_CORNELL_SAMPLE = 400;
+// A launch of many frames: a quarter more waves than are resident (the surplus starts as slots come free and finds
+// tickets left): 20 frames at 720p +1.5 %, 1 024 frames +0.4 %; 150 % the same, 75 % -4 %.
+constexpr uint32_t MULTI_FRAME_SURPLUS_DIV = 4;
+// Tickets: aim at >= 8 per wave of the grid, at most 16 / 8 / 4 units of 4x4 pixels each (launches of many frames / of one
+// or two samples / others).  720p, 1 spp, 8 chains: 64 pixels per ticket 10.0, 128-256 10.15, 384+ 9.96 Gsamples/s.
+constexpr uint32_t TICKETS_PER_WAVE = 8, GRAB_MOST_MULTI_FRAME = 16, GRAB_MOST_FEW_SAMPLES = 8, GRAB_MOST = 4;
+// Regeneration: the batch runs once 32 lanes lack a prepared ray (4K / 16 spp: 24-48 within 1 %, 8 loses 5 %) or idle_min
+// lanes sit idle; in one-sample launches idle_min = min(12, 4800 / serial_cost): 12 idle lanes wait for the batch on the
+// Cornell box (+2 %, serial +5 %), none on 4 096 spheres (12 lanes idle through that loop lose 6 %).
+constexpr uint32_t REGEN_MIN = 32, IDLE_MIN_MOST = 12, IDLE_MIN_COST = 4800;
+// Taking the next PIXEL ahead of time only with >= 8 (frame, pixel) pairs per lane, or in overlapped launches of several
+// samples on small scenes (720p, 16 spp, 8 in flight: +3 %; serial 720p / 1 spp: -13 %; random4096: -7...-19 %).
+constexpr uint32_t PREFETCH_PAIRS_PER_LANE = 8, PREFETCH_SMALL_SCENE_COST = 800;
+}  // namespace tune
+
 // One launch of the path kernel (arguments validated by pt_render): `frames` frames of sample_count samples each,
 // frame f = samples [sample_begin + f * frame_stride, sample_begin + f * frame_stride + sample_count).
 //  * pipelined: a launch of the open burst on the next chain; it writes one plane of sums per frame into the chain's
@@ -470,7 +515,8 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     // one 64-ray pass.  The kernel build that contains it costs the common loop 2-3 %, so it is used where
     // waves drain alone (short launches that do not overlap others) or the scene is large (threshold >= 6 rays).
     const DevSceneF& f = ctx->sf;
-    const uint32_t serial_cost = 25u * (uint32_t)f.ns + 7u * (uint32_t)(f.nax + f.nay + f.naz) + 13u * (uint32_t)f.npg + 35u * (uint32_t)f.nt;
+    const uint32_t serial_cost = tune::COST_SPHERE * (uint32_t)f.ns + tune::COST_AXIS_PLANE * (uint32_t)(f.nax + f.nay + f.naz) +
+                                 tune::COST_PLANE * (uint32_t)f.npg + tune::COST_TRIANGLE * (uint32_t)f.nt;
     {
         // per ray in the lane-parallel form: the broadcast and the reduction, one test per 64 primitives of a kind, and
         // the wait for every 64 beyond the first of a kind, which come from global memory instead of LDS with no other
@@ -479,12 +525,13 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
         // at 150 primitives, where 24 rays already cost more than one pass of the serial loop)
         const uint32_t cs = ((uint32_t)f.ns + 63u) / 64u, cp = ((uint32_t)f.np + 63u) / 64u, ct = ((uint32_t)f.nt + 63u) / 64u;
         const uint32_t from_global = (cs > 1u ? cs - 1u : 0u) + (cp > 1u ? cp - 1u : 0u) + (ct > 1u ? ct - 1u : 0u);
-        const uint32_t per_ray = 40u + 27u * cs + 15u * cp + 37u * ct + 60u * (from_global < 2u ? from_global : 2u) + 25u * (from_global > 2u ? from_global - 2u : 0u);
+        const uint32_t per_ray = tune::FEW_BASE + tune::FEW_PER_64_SPHERES * cs + tune::FEW_PER_64_PLANES * cp + tune::FEW_PER_64_TRIANGLES * ct +
+                                 tune::FEW_GLOBAL_WAIT_FIRST * (from_global < 2u ? from_global : 2u) + tune::FEW_GLOBAL_WAIT_NEXT * (from_global > 2u ? from_global - 2u : 0u);
         const uint32_t few = serial_cost / per_ray;
-        a.few_max = few > 32u ? 32u : few;
+        a.few_max = few > tune::FEW_MAX_CAP ? tune::FEW_MAX_CAP : few;
         // (serial launches: 720p, 1 spp +15 % with it; 4K, 16 spp, 340 samples per resident lane, -3 %)
-        const uint64_t per_lane = ((uint64_t)ctx->width * ctx->height * sample_count * frames) / ((uint64_t)ctx->compute_units * 6u * 256u);
-        if ((pipelined || per_lane >= 100u) && a.few_max < 6u) a.few_max = 0u;
+        const uint64_t per_lane = ((uint64_t)ctx->width * ctx->height * sample_count * frames) / ((uint64_t)ctx->compute_units * tune::LANES_PER_CU_AT_6_WAVES);
+        if ((pipelined || per_lane >= tune::FEW_LONG_LAUNCH_SAMPLES_PER_LANE) && a.few_max < tune::FEW_MIN_THRESHOLD_WHEN_OVERLAPPED) a.few_max = 0u;
         if (ctx->knob_few_max >= 0) a.few_max = (uint32_t)ctx->knob_few_max;
     }
     const bool few = a.few_max > 0u;
@@ -506,16 +553,16 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     //  large scene therefore counts as many: its brute-force cost relative to the Cornell box's.)
     uint32_t cap = resident;
     if (pipelined) {
-        const uint64_t weight = serial_cost > 400u ? serial_cost / 400u : 1u;
-        const uint64_t by_work = ((uint64_t)ctx->width * ctx->height * sample_count * frames * weight) / (256u * 14u);
+        const uint64_t weight = serial_cost > tune::GRID_COST_OF_A_CORNELL_SAMPLE ? serial_cost / tune::GRID_COST_OF_A_CORNELL_SAMPLE : 1u;
+        const uint64_t by_work = ((uint64_t)ctx->width * ctx->height * sample_count * frames * weight) / (256u * tune::GRID_SAMPLES_PER_LANE);
         // (the factor is against 6 waves/SIMD: a build that fits 7 has the same optimum in blocks)
         const uint32_t six = ctx->compute_units * 6u;
-        const uint32_t by_fill = ((resident < six ? resident : six) * 27u) / (20u * ctx->flight);
+        const uint32_t by_fill = ((resident < six ? resident : six) * tune::GRID_FILL_NUM) / (tune::GRID_FILL_DEN * ctx->flight);
         const uint32_t want = by_work > by_fill ? (by_work > resident ? resident : (uint32_t)by_work) : by_fill;
         if (want < cap) cap = want;
         // (a launch of many frames: a quarter more waves than are resident -- the surplus starts as slots come free and
         //  finds tickets left: 20 frames at 720p +1.5 %, 1024 frames +0.4 %; 150 % the same, 75 % -4 %)
-        if (frames > 1u && cap == resident) cap = resident + resident / 4u;
+        if (frames > 1u && cap == resident) cap = resident + resident / tune::MULTI_FRAME_SURPLUS_DIV;
     }
     // work unit = 4x4 pixels; a ticket is at least units_per_grab of them.  Default: aim at >= 8
     // tickets per wave of the grid, but never more than one 8x8 tile per ticket -- two for launches of one
@@ -524,7 +571,11 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     const uint32_t units = a.num_tiles * 4u * frames;
     uint32_t upg;
     if (prm->pixels_per_wave) upg = (prm->pixels_per_wave + 15u) / 16u;
-    else { const uint32_t most = frames > 1u ? 16u : (sample_count <= 2u ? 8u : 4u); upg = units / (cap * 4u * 8u); upg = upg > most ? most : upg; }
+    else {
+        const uint32_t most = frames > 1u ? tune::GRAB_MOST_MULTI_FRAME : (sample_count <= 2u ? tune::GRAB_MOST_FEW_SAMPLES : tune::GRAB_MOST);
+        upg = units / (cap * 4u * tune::TICKETS_PER_WAVE);
+        upg = upg > most ? most : upg;
+    }
     a.units_per_grab = upg < 1u ? 1u : (upg > 65536u ? 65536u : upg);
     uint32_t blocks = (units / a.units_per_grab + 3u) / 4u;  // no more waves than tickets ...
     if (blocks > cap) blocks = cap;                          // ... and no more than the cap
@@ -536,12 +587,13 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     // pixel waits for its next one; in one-sample launches of small scenes every path end is such a wait, and the
     // pull + camera ray (~150 instructions) then waits for 12 idle lanes (+2 %, serial +5 %) -- unless a trip of
     // waiting costs more than that (large scenes: 12 lanes idle through a 4096-sphere loop lose 6 %).
-    a.regen_min = 32u;
+    a.regen_min = tune::REGEN_MIN;
     a.idle_min = 1u;
-    if (sample_count == 1u) { const uint32_t r = 4800u / (serial_cost ? serial_cost : 1u); a.idle_min = r > 12u ? 12u : r; }
+    if (sample_count == 1u) { const uint32_t r = tune::IDLE_MIN_COST / (serial_cost ? serial_cost : 1u); a.idle_min = r > tune::IDLE_MIN_MOST ? tune::IDLE_MIN_MOST : r; }
     // (launches that overlap others lose less to a withheld pixel -- another launch's lanes fill in: 720p, 16 spp, 8 in
     //  flight +3 % with it, `random4096` -7 %)
-    a.prefetch_pixels = ((uint64_t)ctx->width * ctx->height * frames >= (uint64_t)cap * 256u * 8u || (pipelined && sample_count > 1u && serial_cost <= 800u)) ? 1u : 0u;
+    a.prefetch_pixels = ((uint64_t)ctx->width * ctx->height * frames >= (uint64_t)cap * 256u * tune::PREFETCH_PAIRS_PER_LANE ||
+                         (pipelined && sample_count > 1u && serial_cost <= tune::PREFETCH_SMALL_SCENE_COST)) ? 1u : 0u;
     if (ctx->knob_regen_min >= 0) a.regen_min = (uint32_t)ctx->knob_regen_min;
     if (ctx->knob_idle_min >= 0) a.idle_min = (uint32_t)ctx->knob_idle_min;
     if (ctx->knob_prefetch >= 0) a.prefetch_pixels = (uint32_t)ctx->knob_prefetch;
@@ -1102,6 +1154,21 @@ int pt_resolve(PtContext* ctx, uint32_t mode) {
     HIP_TRY(pt_launch_resolve(ctx->accum, ctx->display, npix, ctx->last_acc_mode, mode, ctx->stream));
     ctx->display_bytes = (size_t)npix * (mode == PT_RESOLVE_FLOAT_MEAN ? 16 : mode == PT_RESOLVE_RGB8_PPM ? 3 : 4);
     ctx->history_frames = 0;  // the display no longer continues the history planes
+    return PT_OK;
+}
+
+int pt_resolve_range(PtContext* ctx, uint32_t mode, uint32_t first_pixel, uint32_t pixel_count, void* dev_out) {
+    if (int rc = use(ctx)) return rc;
+    if (!ctx->accum) return fail(PT_ERR_STATE, "no frame allocated");
+    if (mode > PT_RESOLVE_RGB8_PPM) return fail(PT_ERR_INVALID, "unknown resolve mode %u", mode);
+    if (!dev_out) return fail(PT_ERR_INVALID, "dev_out is null");
+    const uint64_t npix = (uint64_t)ctx->width * ctx->height;
+    if ((uint64_t)first_pixel + pixel_count > npix) return fail(PT_ERR_INVALID, "pixels [%u, %u + %u) exceed the frame's %llu", first_pixel, first_pixel, pixel_count, (unsigned long long)npix);
+    if (mode == PT_RESOLVE_FLOAT_MEAN && ((uintptr_t)dev_out & 15u) != 0) return fail(PT_ERR_INVALID, "a float4 output must be 16-byte aligned");
+    if (mode != PT_RESOLVE_FLOAT_MEAN && mode != PT_RESOLVE_RGB8_PPM && ((uintptr_t)dev_out & 3u) != 0) return fail(PT_ERR_INVALID, "an RGBA8 output must be 4-byte aligned");
+    if (int rc = join_chains(ctx)) return rc;
+    if (pixel_count == 0) return PT_OK;
+    HIP_TRY(pt_launch_resolve(ctx->accum + first_pixel, dev_out, pixel_count, ctx->last_acc_mode, mode, ctx->stream));
     return PT_OK;
 }
 

@@ -3,8 +3,10 @@
 The path shards by SAMPLE, not by image region (north_star): every rank keeps the
 whole frame, rank r traces the sample indices `partition(...)` hands it, and the float4
 accumulation buffers (sum r,g,b + sample count in .w, so counts combine in the same reduce) are
-added once per render with a `torch.distributed` reduce — RCCL over xGMI when the tensors live
-on GPUs (backend "nccl"), gloo on CPU in the tests.  Because the RNG is keyed on the absolute
+added once per render with a `torch.distributed` collective — RCCL over xGMI when the tensors live
+on GPUs (backend "nccl"), gloo on CPU in the tests: a reduce to one rank that then resolves the picture
+(`reduce_accum`), or a reduce-scatter after which every rank resolves its own slice of the pixels and the
+4-byte pixels are gathered (`reduce_scatter_accum` + `gather_display`, what bench.py times).  Because the RNG is keyed on the absolute
 sample index, the N-rank image equals the 1-rank image up to FP32 summation order.
 
 Backend-agnostic on purpose: `render_fn(sample_begin, sample_count)` is whatever adds samples to
@@ -53,6 +55,68 @@ def render_split(render_fn: Callable[[int, int], None], total_samples: int, worl
         render_fn(first_sample + begin + done, n)
         done += n
     return count
+
+
+def pixel_slice(npix: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """The pixels [first, first + count) whose sums `reduce_scatter_accum` leaves on `rank`: equal chunks of
+    ceil(npix / world) pixels, the last ranks' chunks cut off at the end of the frame (possibly empty)."""
+    if world_size < 1 or not (0 <= rank < world_size) or npix < 0:
+        raise ValueError("bad slice request")
+    chunk = -(-npix // world_size)
+    first = min(rank * chunk, npix)
+    return first, min(chunk, npix - first)
+
+
+def reduce_scatter_accum(accum) -> Tuple[int, int]:
+    """Sum the accumulation buffers over ranks so that every rank ends up with the sums of ITS slice of the pixels
+    (SURVEY §8e's cheaper collective: each GPU receives and adds 1/N of the frame instead of one GPU receiving all of
+    it).  `accum` is a contiguous float32 tensor [H, W, 4]; on return its pixels [first, first + count) -- the returned
+    pair, `pixel_slice(H * W, world, rank)` -- hold the sums (and sample counts) of all ranks; the other pixels still
+    hold this rank's own.  One `reduce_scatter_tensor` (RCCL over xGMI on GPUs, gloo on CPU), enqueued on the current
+    stream like every torch collective: nothing here synchronises the host."""
+    import torch
+    import torch.distributed as dist
+    npix = accum.numel() // 4
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0, npix
+    world, rank = dist.get_world_size(), dist.get_rank()
+    chunk = -(-npix // world)
+    flat = accum.view(-1)
+    if chunk * world != npix:   # the collective wants equal chunks: pad with zeros (a frame whose pixel count the ranks do not divide)
+        padded = torch.zeros(chunk * world * 4, dtype=accum.dtype, device=accum.device)
+        padded[:npix * 4] = flat
+    else:
+        padded = flat
+    if accum.is_cuda and dist.get_backend() == "gloo":   # (the one-GPU rehearsal of bench.py: gloo's collectives are staged through the host)
+        mine = torch.empty(chunk * 4, dtype=accum.dtype)
+        dist.reduce_scatter_tensor(mine, padded.cpu(), op=dist.ReduceOp.SUM)
+        mine = mine.to(accum.device)
+    else:
+        mine = torch.empty(chunk * 4, dtype=accum.dtype, device=accum.device)
+        dist.reduce_scatter_tensor(mine, padded, op=dist.ReduceOp.SUM)
+    first, count = pixel_slice(npix, world, rank)
+    flat[first * 4:(first + count) * 4] = mine[:count * 4]
+    return first, count
+
+
+def gather_display(display_slice, npix: int):
+    """All ranks' resolved slices (int32 words, 0x00RRGGBB, `pixel_slice` order) -> the whole picture [npix] on every
+    rank: one all-gather of 4 bytes per pixel.  `display_slice` holds ceil(npix / world) words (the tail beyond the
+    rank's pixel count is ignored)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return display_slice[:npix]
+    world = dist.get_world_size()
+    chunk = -(-npix // world)
+    assert display_slice.numel() == chunk
+    if display_slice.is_cuda and dist.get_backend() == "gloo":
+        full = torch.empty(chunk * world, dtype=display_slice.dtype)
+        dist.all_gather_into_tensor(full, display_slice.cpu())
+        return full[:npix].to(display_slice.device)
+    full = torch.empty(chunk * world, dtype=display_slice.dtype, device=display_slice.device)
+    dist.all_gather_into_tensor(full, display_slice)
+    return full[:npix]
 
 
 def reduce_accum(accum, dst: int = 0, all_ranks: bool = False):

@@ -117,6 +117,11 @@ class Renderer:
     def resolve(self, mode: int):
         check(self._L.pt_resolve(self._ctx, mode))
 
+    def resolve_range(self, mode: int, first_pixel: int, pixel_count: int, out):
+        """pt_resolve_range: pixels [first, first + count) of the accumulation buffer into `out`, a CUDA tensor the caller owns."""
+        assert out.is_cuda and out.is_contiguous()
+        check(self._L.pt_resolve_range(self._ctx, mode, first_pixel, pixel_count, C.c_void_p(out.data_ptr())))
+
     def sync(self):
         check(self._L.pt_sync(self._ctx))
 

@@ -303,4 +303,8 @@ BUILTIN = {"cpu_default": cpu_default, "cuda_default": cuda_default,
 
 
 def builtin(name: str, width: int, height: int):
+    """A built-in scene by name; "random<N>" (N spheres of config 5's generator over its floor plane) for any N, e.g. the
+    150- and 1 000-primitive scenes the launch heuristics are swept on ("random149", "random999")."""
+    if name not in BUILTIN and name.startswith("random") and name[6:].isdigit():
+        return random4096(width, height, count=int(name[6:]))
     return BUILTIN[name](width, height)

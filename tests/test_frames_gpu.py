@@ -278,3 +278,28 @@ def test_direct_integrator_counters(gpu):
     ids, _ = gpu.primary_ids()
     light_share = float((ids == 7).mean())                       # the emissive sphere is object 7
     assert abs(c["nee_samples"] / n - (1.0 - light_share)) < 0.01
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """bench.py's N > 1 code path end to end -- schedules, reduce-scatter, per-rank resolve of the own slice
+    (pt_resolve_range), all-gather of the pictures, the per-rank sample-count check -- with two gloo ranks that share this
+    box's one GPU (the numbers mean nothing; the RCCL run on separate GPUs is the driver's)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--cpu-seconds", "0", "--rehearse-on-one-gpu"], capture_output=True, text=True, timeout=280, env=env)
+    assert p.returncode == 0, p.stderr[-1500:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["reduce_bytes_per_rank"] == 1280 * 720 // 2 * 16 and d["gather_bytes_per_rank"] == 1280 * 720 // 2 * 4
+    assert d["reduce_ms"] > 0 and d["display_ms"] > 0
+    l = d["legs"]["cornell_4k_1024spp_strong_split"]
+    assert l["scaling"] == "strong" and l["n_gpus"] == 2 and l["steps_per_rank_max"] == 32 and l["reduce_bytes_per_rank"] == 3840 * 2160 // 2 * 16
+    assert "cpu_default_direct_720p_64spp" not in d["legs"]      # config 1 is a single-GPU leg
