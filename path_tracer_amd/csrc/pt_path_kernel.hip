@@ -519,10 +519,11 @@ __device__ __forceinline__ const PT_CONST KArgs* cold() {
 #ifndef PT_NEE_WAVES
 #define PT_NEE_WAVES 6
 #endif
-// (the plain build with the lane-parallel mode needs 71 VGPRs, 7 waves/SIMD, since its loops use 32-bit offsets; at
-//  73 it was asked for 7 waves, fitted 72 by spilling 31 SGPRs and ran 9 % slower: left alone)
+// (the plain build with the lane-parallel mode: round 2's needed 71 VGPRs and was left alone (asked for 7 waves it
+//  spilled 31 SGPRs and ran 9 % slower).  Round 3's reads the lane's LDS rows together and takes 80-81; its 106 SGPRs
+//  admit 6 waves/SIMD in any case (MI355X_MICROARCH.md, residency), so it is budgeted for 6: 77 VGPRs, nothing spilled)
 #ifndef PT_FEW_WAVES
-#define PT_FEW_WAVES 1
+#define PT_FEW_WAVES 6
 #endif
 // (the light-sampling build without the lane-parallel mode: 76 VGPRs left alone; asked for 7 waves/SIMD it fits 72 with
 //  three spilled registers and runs 3.6 % faster)
@@ -866,11 +867,14 @@ __global__ __launch_bounds__(PT_BLOCK) PT_OCC void pt_path_kernel(const KArgs ka
             const uint64_t pull_mask = __ballot(want);
             if (pull_mask != 0ull && !exhausted) {
                 if (pool_next >= pool_size) {
+                    const uint32_t total_units = shard_units * kc->a.frames;  // a launch of several frames: frame-major
+                    // (round 3: tickets that shrink towards the end of the ticket space, to a fair share of what is left,
+                    //  made the waves run out of work within 125 us of each other instead of 290 -- and the launch no
+                    //  shorter: it ends when its longest path ends, 190-260 us after the last ticket.  Dropped.)
                     const uint32_t need = max(a.units_per_grab, ((uint32_t)__popcll(pull_mask) + 15u) >> 4);
                     uint32_t ticket = 0;
                     if (lane == 0) ticket = atomicAdd(a.work_counter + shard * 32u, need);
                     ticket = __builtin_amdgcn_readfirstlane(ticket);
-                    const uint32_t total_units = shard_units * kc->a.frames;  // a launch of several frames: frame-major
                     if (ticket >= total_units) {
                         exhausted = true;
 #ifdef PT_TRACE
