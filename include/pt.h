@@ -242,8 +242,9 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
                       uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* params);
 /* Frames in flight (1..8, default 1).  The reference's frame loop (main.cu:284-303)
  * serialises launch and display, one frame at a time; there is no counterpart.
- * With n > 1 a PT_ACC_SUM path call is a FRAME that the library may hold back and
- * overlap with others:
+ * With n > 1 a path call -- sums, or the reference's running mean (PT_ACC_RUNNING_MEAN,
+ * one sample per call) -- is a FRAME that the library may hold back and overlap with
+ * others:
  *  - Consecutive calls with the same parameters and sample count whose sample
  *    ranges are equally spaced -- each starting where the one before it ended (the
  *    reference's loop is exactly that), or a fixed distance further on (a rank of a
@@ -259,7 +260,9 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
  *    its chain, and a fold pass behind it adds them to the accumulation buffer one
  *    frame after the other (and, with fused_rgba8, makes every frame's display from
  *    the sums as they stand after it).  The fold passes run in launch order, so
- *    the buffer receives acc += frame k for k = 0, 1, 2, ... exactly as under serial
+ *    the buffer receives acc += frame k -- or, for the running mean, acc = frame k * t
+ *    + acc * (1 - t) with t = 1 / (frame_count + 1), frame_count == 0 overwriting,
+ *    raytracer_kernel.cu:297-304 -- for k = 0, 1, 2, ... exactly as under serial
  *    launches: the image is bit-identical to the n = 1 image, and the display made
  *    for frame k is the mean of samples 0..k as in the reference's loop.  The newest
  *    display is in the display buffer (pt_readback); the ones the same fold pass
@@ -281,10 +284,13 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
  * slower than 3), so the request is GRANTED only up to what the variable, as
  * the library finds it at pt_create, leaves room for: 3 chains when it is unset
  * or <= 7, GPU_MAX_HW_QUEUES - 4 beyond that.  The call still returns PT_OK;
- * pt_frames_in_flight() returns the number in effect.  Memory: per chain one
- * plane of the frame's size (16 B per pixel) for every frame a launch may hold
- * (944 MB at 1280x720, at most 2 GiB), plus 4 B per pixel and frame for the
- * display history (one per context).
+ * pt_frames_in_flight() returns the number in effect.  Memory: per chain that is
+ * used, one plane of the frame's size (16 B per pixel) for every frame a launch may
+ * hold (944 MB at 1280x720, at most 2 GiB), plus 4 B per pixel and frame for the
+ * display history (one per context); allocated on the chain's first launch, whole
+ * (so that no later launch of the frame loop reallocates), freed when the frame is
+ * resized.  When the device has no room for them the frames are rendered by
+ * serial launches instead: same sums, same displays, no history.
  *
  * Large calls.  Within a frame a pixel's samples belong to one lane, so one launch
  * with many samples per pixel over few pixels per lane (2.3 at 1280x720) ends with
@@ -293,7 +299,8 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
  * up to 128 samples, 4 samples per frame beyond) of multi-frame launches: with
  * n > 1 they join the open burst like any other frame; with n = 1 the call is a
  * burst of its own on three chains (GPU_MAX_HW_QUEUES - 4 of them when the
- * environment grants more, up to 8), folded (and, with fused_rgba8, displayed)
+ * environment grants more, up to 8; each chain's planes sized by what the call puts
+ * on it: 16 planes for 16 samples), folded (and, with fused_rgba8, displayed)
  * before pt_render returns, so nothing stays in flight.  The cut depends only on
  * the call's arguments and the frame size: the image is reproducible, the same
  * bit for bit for every n, and equals the single launch's up to float summation
@@ -346,6 +353,13 @@ int pt_sync(PtContext* ctx);
  * (The reference is single-GPU, main.cu:30; no counterpart.) */
 int pt_reduce(PtContext* ctx, void* nccl_comm, int root);
 
+/* The cheaper combine of SURVEY §8e for the same hosts: ncclReduceScatter in place, after which THIS rank's slice of
+ * the buffer -- pixels [*first_pixel, *first_pixel + *pixel_count) = the rank-th of `world` equal slices, row-major --
+ * holds the sums and counts of all ranks (the other pixels keep this rank's own); follow with
+ * pt_resolve_range on that slice and gather the 4-byte pixels.  `rank` / `world` are the communicator's; the pixel
+ * count must be divisible by `world` (PT_ERR_INVALID otherwise: use pt_reduce).  Asynchronous.  No counterpart. */
+int pt_reduce_scatter(PtContext* ctx, void* nccl_comm, uint32_t rank, uint32_t world, uint32_t* first_pixel, uint32_t* pixel_count);
+
 /* Device pointers for callers that drive collectives themselves. */
 void* pt_accum_device_ptr(PtContext* ctx);
 void* pt_display_device_ptr(PtContext* ctx);
@@ -388,6 +402,13 @@ int pt_valu_peak(PtContext* ctx, uint32_t packed, uint32_t iters, double* out_tf
  * stream nobody chose (pt_set_stream / pt_use_own_stream) moves to the null stream
  * on its first call through this function, so the caller's own kernels and copies
  * on `output` stay ordered with the launch as they were.
+ * Frames in flight: after pt_set_frames_in_flight(n > 1) consecutive calls that name
+ * the same `output` are frames like pt_render's -- held back, collected into one
+ * launch, the running mean applied by the fold pass in frame order, bit-identical
+ * to one launch per call.  `output` then stays bound to the context until the next
+ * entry point other than this one, which first folds what is held back into it; a
+ * caller that reads `output` itself calls pt_flush() before (a loop that shows
+ * every frame therefore gets serial launches, as with n = 1, where nothing changes).
  * The function returns void like the reference's; its error channel is
  * pt_last_error(), which is empty after a launch that was enqueued (every entry
  * point clears the thread's message on entry), so

@@ -20,7 +20,7 @@ SYMBOLS = [
     "pt_readback_accum", "pt_history_frames", "pt_readback_history", "pt_upload_accum", "pt_sync", "pt_accum_device_ptr", "pt_display_device_ptr",
     "pt_primary_ids", "pt_counters", "pt_reset_counters", "pt_valu_peak", "pt_make_current",
     "launchRenderKernel", "pt_builtin_scene", "pt_set_frames_in_flight", "pt_frames_in_flight", "pt_path_launches", "pt_flush",
-    "pt_fly_camera_step", "pt_reduce", "pt_render_noalloc", "pt_path_length_histogram", "pt_resolve_range",
+    "pt_fly_camera_step", "pt_reduce", "pt_render_noalloc", "pt_path_length_histogram", "pt_resolve_range", "pt_reduce_scatter",
 ]
 
 _lib = None
@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
     L.pt_frames_in_flight.restype = u32
     L.pt_flush.argtypes = [ctx]
     L.pt_reduce.argtypes = [ctx, vp, C.c_int]
+    L.pt_reduce_scatter.argtypes = [ctx, vp, u32, u32, C.POINTER(u32), C.POINTER(u32)]
     L.pt_fly_camera_step.argtypes = [C.POINTER(abi.PtCamera), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double, u32]
     L.pt_builtin_scene.argtypes = [C.c_char_p, u32, u32, C.POINTER(abi.PtSceneSoA), C.POINTER(abi.PtCamera)]
     _lib = L

@@ -1289,6 +1289,31 @@ int pt_reduce(PtContext* ctx, void* nccl_comm, int root) {
     return PT_OK;
 }
 
+int pt_reduce_scatter(PtContext* ctx, void* nccl_comm, uint32_t rank, uint32_t world, uint32_t* first_pixel, uint32_t* pixel_count) {
+    if (int rc = use(ctx)) return rc;
+    if (!nccl_comm) return fail(PT_ERR_INVALID, "communicator is null");
+    if (!ctx->accum) return fail(PT_ERR_STATE, "no frame allocated");
+    if (world == 0 || rank >= world) return fail(PT_ERR_INVALID, "rank %u of %u", rank, world);
+    const uint64_t npix = (uint64_t)ctx->width * ctx->height;
+    if (npix % world != 0) return fail(PT_ERR_INVALID, "pt_reduce_scatter works in place on equal slices: %llu pixels are not divisible by %u ranks (use pt_reduce)", (unsigned long long)npix, world);
+    // ncclResult_t ncclReduceScatter(send, recv, recvcount, datatype, op, comm, stream); in place: recv == send + rank * recvcount
+    using rs_fn = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static void* fn = nullptr;
+    if (!fn) {
+        fn = dlsym(RTLD_DEFAULT, "ncclReduceScatter");
+        if (!fn) if (void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL)) fn = dlsym(h, "ncclReduceScatter");
+        if (!fn) return fail(PT_ERR_STATE, "RCCL is not loaded in this process (ncclReduceScatter not found)");
+    }
+    if (int rc = join_chains(ctx)) return rc;
+    const uint64_t slice = npix / world;
+    const int nccl_float = 7, nccl_sum = 0;  // ncclFloat32, ncclSum (rccl.h)
+    const int res = ((rs_fn)fn)(ctx->accum, ctx->accum + (size_t)rank * slice, (size_t)slice * 4u, nccl_float, nccl_sum, nccl_comm, ctx->stream);
+    if (res != 0) return fail(PT_ERR_HIP, "RCCL ncclReduceScatter failed with ncclResult_t %d", res);
+    if (first_pixel) *first_pixel = (uint32_t)(rank * slice);
+    if (pixel_count) *pixel_count = (uint32_t)slice;
+    return PT_OK;
+}
+
 void* pt_accum_device_ptr(PtContext* ctx) { return ctx ? (void*)ctx->accum : nullptr; }
 void* pt_display_device_ptr(PtContext* ctx) { return ctx ? ctx->display : nullptr; }
 

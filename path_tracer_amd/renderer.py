@@ -89,6 +89,12 @@ class Renderer:
         """In-place RCCL sum of the accumulation buffer over the communicator's ranks (root < 0: all-reduce)."""
         check(self._L.pt_reduce(self._ctx, C.c_void_p(nccl_comm), int(root)))
 
+    def reduce_scatter(self, nccl_comm, rank: int, world: int):
+        """In-place RCCL reduce-scatter: returns (first_pixel, pixel_count) of the slice that now holds all ranks' sums."""
+        first, count = C.c_uint32(), C.c_uint32()
+        check(self._L.pt_reduce_scatter(self._ctx, C.c_void_p(nccl_comm), rank, world, C.byref(first), C.byref(count)))
+        return first.value, count.value
+
     def flush(self):
         """Fold the in-flight chains into the accumulation buffer (asynchronous)."""
         check(self._L.pt_flush(self._ctx))
