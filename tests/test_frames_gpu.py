@@ -303,3 +303,43 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     l = d["legs"]["cornell_4k_1024spp_strong_split"]
     assert l["scaling"] == "strong" and l["n_gpus"] == 2 and l["steps_per_rank_max"] == 32 and l["reduce_bytes_per_rank"] == 3840 * 2160 // 2 * 16
     assert "cpu_default_direct_720p_64spp" not in d["legs"]      # config 1 is a single-GPU leg
+
+
+def test_random_mixes_of_sum_and_mean_frames_equal_the_serial_loop(gpu):
+    """Any sequence of sum frames, running-mean frames (frame counts that continue, restart at 0 or jump), flushes,
+    resolves and changes of the number of chains gives, bit for bit, the buffer and the display that the same calls give
+    with one serial launch per frame."""
+    sc, cam = scenes.cuda_default(96, 54)
+    for seed in (1, 2, 3):
+        rng = np.random.default_rng(20261111 + seed)
+        ops, sample, frame = [], 0, 0
+        for _ in range(120):
+            k = int(rng.integers(0, 10))
+            if k <= 3:
+                n = int(rng.integers(1, 4)); ops.append(("sum", sample, n, int(rng.integers(0, 2)))); sample += n
+            elif k <= 6:
+                if rng.integers(0, 8) == 0: frame = int(rng.integers(0, 3)) * 5      # restart (0 overwrites) or jump
+                ops.append(("mean", frame, 1, int(rng.integers(0, 2)))); frame += 1
+            elif k == 7: ops.append(("flush",))
+            elif k == 8: ops.append(("resolve",))
+            else: ops.append(("flight", int(rng.integers(1, 4))))
+
+        def run(pipelined):
+            _setup(gpu, sc, cam)
+            gpu.set_frames_in_flight(1)
+            for op in ops:
+                if op[0] == "sum": gpu.render(op[1], op[2], abi.render_params(max_depth=8, fused_rgba8=op[3]))
+                elif op[0] == "mean": gpu.render(op[1], 1, abi.render_params(max_depth=8, fused_rgba8=op[3], acc_mode=abi.ACC_RUNNING_MEAN))
+                elif op[0] == "flush": gpu.flush()
+                elif op[0] == "resolve": gpu.resolve(abi.RESOLVE_RGBA8_CUDA)
+                elif pipelined: gpu.set_frames_in_flight(op[1])
+            acc = gpu.accum()
+            return acc, gpu.resolve_to_host(abi.RESOLVE_RGBA8_CUDA)
+        try:
+            want, want_rgba = run(False)
+            got, got_rgba = run(True)
+        finally:
+            gpu.set_frames_in_flight(1)
+        assert np.isfinite(want).all()
+        assert np.array_equal(got, want), seed
+        assert np.array_equal(got_rgba, want_rgba), seed
