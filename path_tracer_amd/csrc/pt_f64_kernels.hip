@@ -144,8 +144,13 @@ __device__ bool visible(const DevSceneD& sc, D3 from, D3 to) {
 // light * colour*cos*50/d^2), background 0.2.  One thread = one pixel, samples in a loop.
 // COUNT: the instrumented build (PT_FLAG_COUNTERS) adds its event counts to `counters` (PtCounters layout): samples,
 // rays (primary + shadow), hits (primary), nee_samples (light samples drawn), shadow_rays (Scene::isVisible calls).
+// Register budget: left alone the kernel takes 134 VGPRs (3 waves/SIMD); asked for 4 it fits 126 with six spilled and
+// runs 6 % faster (21.8 -> 23.2 Gsamples/s on BASELINE config 1); 5 waves (96 VGPRs, 39 spilled) lose 4 %.
+#ifndef PT_DIRECT_WAVES
+#define PT_DIRECT_WAVES 4
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(256) void pt_direct_kernel(const DevSceneD sc, const DevCamD cam, float4* accum, uint32_t s0,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_DIRECT_WAVES))) void pt_direct_kernel(const DevSceneD sc, const DevCamD cam, float4* accum, uint32_t s0,
                                                         uint32_t count, uint32_t seed, uint64_t* counters) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= cam.width * cam.height) return;
