@@ -5,7 +5,8 @@ import collections, csv, glob, json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def pmc(d):
     agg = collections.defaultdict(float); disp = set(); names = set()
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    # (gpurun merges a call's files into gpurun_out/ beside those of earlier calls: the newest CSV is this run's)
+    for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             if "pt_path_kernel" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"]); names.add(r["Kernel_Name"].split("(")[0])
