@@ -620,10 +620,10 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
         const size_t waves = (size_t)blocks * 4u;
         if (ctx->trace_waves < waves) {
             if (ctx->trace) HIP_TRY(hipFree(ctx->trace));
-            HIP_TRY(hipMalloc((void**)&ctx->trace, waves * 128));
+            HIP_TRY(hipMalloc((void**)&ctx->trace, waves * PT_TRACE_WORDS * 8u));
             ctx->trace_waves = waves;
         }
-        HIP_TRY(hipMemsetAsync(ctx->trace, 0, waves * 128, stream));
+        HIP_TRY(hipMemsetAsync(ctx->trace, 0, waves * PT_TRACE_WORDS * 8u, stream));
         a.trace = ctx->trace;
     } else a.trace = nullptr;
     PROF(ctx, 1, pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, few, blocks, stream));
@@ -636,7 +636,7 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
         ctx->burst++;
     }
     if (trace_file) {
-        std::vector<uint64_t> host((size_t)blocks * 4u * 16u);
+        std::vector<uint64_t> host((size_t)blocks * 4u * PT_TRACE_WORDS);
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpy(host.data(), ctx->trace, host.size() * 8, hipMemcpyDeviceToHost));
         if (FILE* f = fopen(trace_file, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }

@@ -110,6 +110,10 @@ constexpr uint32_t PT_SCRATCH_BYTES = 4096;
 // Resolves (once per device, with that device current) and returns the device address of this GPU's copy.
 hipError_t pt_scratch_setup(int device, uint32_t** out);
 
+// Per-wave record of the PT_TRACE kernel builds (tools/gpu_trace.py), in 8-byte words: 16 of totals, then a ring of the
+// wave's last 256 trips as 32-bit entries (time since the wave's start in 10-ns ticks << 7 | lanes alive).
+constexpr uint32_t PT_TRACE_WORDS = 16u + 128u;
+
 // Most dynamic LDS a path-kernel workgroup (one wave) takes: 28 waves per CU x 5.5 KB stay within the CU's 160 KB, so
 // LDS never costs a wave of occupancy.  The occupancy query is made with this figure.
 constexpr uint32_t PT_LDS_MAX_BYTES = 5632;

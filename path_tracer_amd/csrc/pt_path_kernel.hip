@@ -51,7 +51,9 @@
 #define PT_FEWFAST 1
 #endif
 // (round 3, measured and dropped: s_setprio 2 / 3 for waves that hold a path of depth >= 6 / 10 / 16 / 24, always or
-//  once the tickets are gone: -1 ... +0.6 %; no hashes for a smooth metal's unused draws in the lane-parallel builds:
+//  once the tickets are gone: -1 ... +0.6 %; graded 1 / 2 / 3 by the wave's deepest path (>= 4 / 10 / 20 and >= 2 / 5 / 10)
+//  once the tickets are gone: -3 % on serial frames, +-1 % on 20 frames, and the per-trip log of tools/gpu_trace.py shows
+//  the favoured waves' trips as long as before -- the instruction arbiter of this part does not act on it; no hashes for a smooth metal's unused draws in the lane-parallel builds:
 //  +0.2 %)
 
 // ---- scratch of the entry point that allocates nothing (pt_render_noalloc, include/pt.h) ------------------
@@ -626,6 +628,10 @@ __device__ __forceinline__ void pt_path_body(const KArgs& kargs) {
         float t_hit = T_BEST_INIT; int id_hit = -1;
         const uint64_t alive_mask = __ballot(alive);
 #ifdef PT_TRACE
+        if (a.trace && lane == 0) {   // the trip's start, in the ring of the wave's last 256 trips
+            uint32_t* ring = (uint32_t*)(a.trace + (size_t)(blockIdx.x * (PT_BLOCK / 64u) + (threadIdx.x >> 6)) * PT_TRACE_WORDS + 16u);
+            ring[tr_trips & 255u] = ((uint32_t)(wall_clock64() - tr_start) << 7) | (uint32_t)__popcll(alive_mask);
+        }
         tr_trips++; tr_lane_trips += (uint32_t)__popcll(alive_mask);
         tr_in_few = (uint32_t)__popcll(alive_mask) <= a.few_max;
         if (tr_in_few) { if (!tr_few) tr_few = wall_clock64(); tr_few_trips++; tr_few_rays += (uint32_t)__popcll(alive_mask); }
@@ -985,7 +991,7 @@ __device__ __forceinline__ void pt_path_body(const KArgs& kargs) {
 
 #ifdef PT_TRACE
     if (a.trace && lane == 0) {
-        uint64_t* tr = a.trace + (size_t)(blockIdx.x * (PT_BLOCK / 64u) + (threadIdx.x >> 6)) * 16u;
+        uint64_t* tr = a.trace + (size_t)(blockIdx.x * (PT_BLOCK / 64u) + (threadIdx.x >> 6)) * PT_TRACE_WORDS;
         tr[0] = tr_start; tr[1] = tr_exh; tr[2] = tr_few; tr[3] = wall_clock64();
         tr[4] = tr_trips; tr[5] = tr_few_trips; tr[6] = tr_few_rays; tr[7] = tr_lane_trips;
         tr[8] = tc_regen; tr[9] = tc_isect; tr[10] = tc_shade; tr[11] = tf_regen; tr[12] = tf_isect; tr[13] = tf_shade;

@@ -17,8 +17,9 @@ for name, (w, h), spp, frames in CASES:
     r.set_frames_in_flight(3 if frames > 1 else 1)      # frames > 1: one launch of that many frames (the last launch is traced)
     for i in range(3 if frames == 1 else frames): r.render(i * spp, spp, abi.render_params(fused_rgba8=1))
     r.sync()
-    t = np.fromfile("/tmp/pt_trace.bin", dtype=np.uint64).reshape(-1, 16)
-    t = t[t[:, 0] > 0]
+    raw = np.fromfile("/tmp/pt_trace.bin", dtype=np.uint64).reshape(-1, 16 + 128)   # PT_TRACE_WORDS (pt_device.h)
+    raw = raw[raw[:, 0] > 0]
+    t, ring = raw[:, :16], raw[:, 16:].copy().view(np.uint32)                        # ring: the wave's last 256 trips
     t0 = t[:, 0].min()
     us = lambda x: (x.astype(np.float64) - float(t0)) / 100.0   # 100 MHz
     start, exh, few, end = us(t[:, 0]), us(t[:, 1]), us(t[:, 2]), us(t[:, 3])
@@ -49,6 +50,30 @@ for name, (w, h), spp, frames in CASES:
         tc, tf = t[i, 8:11].astype(np.float64), t[i, 11:14].astype(np.float64)
         print(f"        cycles per few-trip: regen {tf[0] / ft:.0f} isect {tf[1] / ft:.0f} shade {tf[2] / ft:.0f};  per normal trip: regen {(tc[0] - tf[0]) / nt:.0f} isect {(tc[1] - tf[1]) / nt:.0f} shade {(tc[2] - tf[2]) / nt:.0f};"
               f"  all cycles {tc.sum():.0f} over {end[i] - start[i]:.1f} us = {tc.sum() / max(end[i] - start[i], 1e-9) / 1e3:.2f} GHz; few rays {int(frays[i])}")
+    # the last waves trip by trip: when each trip began (us since the launch began) and how many lanes traced in it
+    for i in late[-3:]:
+        n = int(trips[i]); k = min(n, 256)
+        e = np.array([ring[i][j & 255] for j in range(n - k, n)], dtype=np.uint64)
+        when, lanes = start[i] + (e >> np.uint64(7)).astype(np.float64) / 100.0, (e & np.uint64(127)).astype(int)
+        dur = np.diff(np.append(when, end[i]))
+        print(f"     trips of the wave that ends at {end[i]:.1f} us (start us : lanes : duration us), last {min(k, 72)} of {n}:")
+        print("       " + "  ".join(f"{w:.0f}:{l}:{d:.1f}" for w, l, d in list(zip(when, lanes, dur))[-72:]))
+        for lo, hi in ((33, 64), (9, 32), (3, 8), (1, 2)):
+            m = (lanes >= lo) & (lanes <= hi)
+            if m.any(): print(f"       trips with {lo}-{hi} lanes: {int(m.sum())}, mean {dur[m].mean():.2f} us, median {np.median(dur[m]):.2f}")
+    # over all waves: mean trip duration by lanes alive and by when the trip began (tenths of the span)
+    allw, alll, alld = [], [], []
+    for i in range(len(t)):
+        n = int(trips[i]); k = min(n, 256)
+        if k == 0: continue
+        e = np.array([ring[i][j & 255] for j in range(n - k, n)], dtype=np.uint64) if n > 256 else ring[i][:k].astype(np.uint64)
+        w = start[i] + (e >> np.uint64(7)).astype(np.float64) / 100.0
+        allw.append(w); alll.append((e & np.uint64(127)).astype(int)); alld.append(np.diff(np.append(w, end[i])))
+        if len(allw) >= 3000: break
+    allw, alll, alld = np.concatenate(allw), np.concatenate(alll), np.concatenate(alld)
+    edges = np.linspace(0, end.max(), 11)
+    print("   mean trip duration (us) / mean lanes alive, by tenth of the span in which the trip began (first 3000 waves):")
+    print("      " + "  ".join(f"{alld[(allw >= a_) & (allw < b_)].mean():.2f}/{alll[(allw >= a_) & (allw < b_)].mean():.0f}" if ((allw >= a_) & (allw < b_)).any() else "-" for a_, b_ in zip(edges[:-1], edges[1:])))
     # how much of the chip is busy over time
     grid = np.linspace(0, end.max(), 21)
     act = [(int(((start <= g) & (end > g)).sum())) for g in grid]
