@@ -224,13 +224,13 @@ def main() -> int:
             r.set_frames_in_flight(1)
             n_serial = min(my_steps, 128)
             torch.cuda.synchronize()
-            ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev2.record()
+            sv0, sv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # (ev2 / ev3 are the combine's)
+            sv0.record()
             for s0, n in sched[Wm:Wm + n_serial]:
                 r.render(s0, n, params)
-            ev3.record()
+            sv1.record()
             torch.cuda.synchronize()
-            serial_ms = ev2.elapsed_time(ev3) / n_serial
+            serial_ms = sv0.elapsed_time(sv1) / n_serial
         # the parts of the timed region, from the events (device time on this rank's stream): render = first launch to last
         # fold pass; reduce = the reduce-scatter behind it; display = this rank's resolve + the all-gather of the pictures
         render_s = ev0.elapsed_time(ev1) * 1e-3 if world > 1 else elapsed
