@@ -12,8 +12,9 @@ making every frame's RGBA8 display on the way: same sums and same pictures as on
           disjoint sample indices, then the float4 accumulation buffers are combined once with an
           RCCL reduce-scatter (every rank receives and adds the sums of 1/N of the pixels), each rank
           resolves its own slice and the 4-byte pixels are all-gathered (inside the timed region;
-          `reduce_ms` and `display_ms` report the two parts from HIP events, no host synchronisation
-          between the render and the closing barrier).
+          `render_ms`, `reduce_ms` and `display_ms` report the parts on rank 0's stream from HIP events
+          -- a rank that ends its frames early waits inside the reduce-scatter for the slowest -- with no
+          host synchronisation between the render and the closing barrier).
 BASELINE's metric is quoted "at 1280x720 & 4K", and north_star's scaling target is defined on
 config 3 (4K at 1024 spp, sample-split with one RCCL sum-reduce), so every run also carries that
 workload as a second leg under `legs`: 3840x2160, 16 spp per step, 64 steps = 1024 spp, the steps
@@ -237,9 +238,12 @@ def main() -> int:
         reduce_s = ev1.elapsed_time(ev2) * 1e-3 if world > 1 else 0.0
         display_s = ev2.elapsed_time(ev3) * 1e-3 if world > 1 else 0.0
         if world > 1:
-            t = torch.tensor([elapsed, frame_ms, render_s, reduce_s, display_s], device="cuda", dtype=torch.float64)
+            # MAX over ranks of the timed region and of the frame time; the three parts stay rank 0's own (they follow one
+            # another on its stream, so they add up to no more than the region; a rank that finishes its frames early
+            # spends the difference inside the reduce-scatter, waiting for the slowest)
+            t = torch.tensor([elapsed, frame_ms], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed, frame_ms, render_s, reduce_s, display_s = (float(v) for v in t)
+            elapsed, frame_ms = (float(v) for v in t)
         out = {"workload": workload, "scene": scene_name, "width": W, "height": H, "spp_per_step": spp, "max_depth": max_depth,
                "steps": K, "warmup": Wm, "scaling": scaling if world > 1 else "weak", "frames_in_flight": flight,
                "elapsed_s": elapsed, "total_steps": total_steps, "samples_per_step": W * H * spp,
@@ -373,7 +377,7 @@ def main() -> int:
             "mrays_per_s": round(head["value"] * head["rays_per_sample"], 1), "rays_per_sample": round(head["rays_per_sample"], 4),
             "roofline": roofline(head, True),
         }
-        if world > 1:  # the collective and the rest of the timed region, apart (max over ranks)
+        if world > 1:  # the collective and the rest of the timed region, apart (rank 0's stream; the region itself is the MAX over ranks)
             result["render_ms"] = round(head["render_ms"], 4)
             result["reduce_ms"] = round(head["reduce_ms"], 4)
             result["display_ms"] = round(head["display_ms"], 4)

@@ -300,7 +300,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["reduce_bytes_per_rank"] == 1280 * 720 // 2 * 16 and d["gather_bytes_per_rank"] == 1280 * 720 // 2 * 4
     assert d["reduce_ms"] > 0 and d["display_ms"] > 0
-    # the three parts follow one another on one stream inside the timed region: together they cannot exceed it
+    # the three parts follow one another on rank 0's stream inside the timed region: together they cannot exceed it
     assert d["host_and_barrier_ms"] >= 0, d
     l = d["legs"]["cornell_4k_1024spp_strong_split"]
     assert l["scaling"] == "strong" and l["n_gpus"] == 2 and l["steps_per_rank_max"] == 32 and l["reduce_bytes_per_rank"] == 3840 * 2160 // 2 * 16
