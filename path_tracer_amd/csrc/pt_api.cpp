@@ -1119,7 +1119,13 @@ int pt_render(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, cons
 
 int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32_t height, uint32_t sample_begin,
                       uint32_t sample_count, const PtRenderParams* prm) {
-    if (int rc = use(ctx)) return rc;
+    // (not use(): that would first fold frames a launchRenderKernel caller left in flight -- launches on other streams,
+    //  possibly the chains' first allocation.  Frames in flight are refused below, whoever left them.)
+    pt_clear_error();
+    if (!ctx) return fail(PT_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->burst != 0 || ctx->pending.frames != 0) return fail(PT_ERR_STATE, "frames are in flight: call pt_flush first (folding them launches on other streams)");
+    if (int rc = end_shim_binding(ctx)) return rc;   // nothing is in flight: this only gives the context its own buffer back
     if (!prm) return fail(PT_ERR_INVALID, "params is null");
     if (!accum_float4 || ((uintptr_t)accum_float4 & 15u) != 0) return fail(PT_ERR_INVALID, "the accumulation buffer must be a 16-byte aligned device pointer");
     if (!ctx->have_scene) return fail(PT_ERR_STATE, "no scene uploaded");
@@ -1140,7 +1146,6 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
     if (prm->max_depth == 0) return fail(PT_ERR_INVALID, "max_depth must be at least 1");
     if (prm->acc_mode == PT_ACC_RUNNING_MEAN && sample_count != 1)
         return fail(PT_ERR_INVALID, "the running-mean mode adds one sample per launch, like renderKernel");
-    if (ctx->burst != 0 || ctx->pending.frames != 0) return fail(PT_ERR_STATE, "frames are in flight: call pt_flush first (folding them launches on other streams)");
     if (!ctx->scratch) return fail(PT_ERR_STATE, "the scratch array was not resolved at pt_create");
     return launch_path(ctx, sample_begin, sample_count, prm, (float4*)accum_float4);
 }

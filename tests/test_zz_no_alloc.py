@@ -103,6 +103,17 @@ def test_no_alloc_entry_point_matches_pt_render():
         r.render_noalloc(big.data_ptr(), 40, 1, p)
         r.sync()
         assert np.all(big.cpu().numpy()[..., 3] == 41)
+        # frames that launchRenderKernel left in flight are refused the same way, before anything is folded or allocated
+        out = torch.zeros((180, 320, 4), device="cuda", dtype=torch.float32)
+        torch.cuda.synchronize()
+        launches = r.path_launches()
+        r.launch_render_kernel(out.data_ptr(), 0)
+        r.launch_render_kernel(out.data_ptr(), 1)          # two frames held back on `out`
+        refused(abi.PT_ERR_STATE, "pt_flush first", ptr, 320, 180, 0, 1, C.byref(p))
+        assert r.path_launches() == launches                # the refusal launched nothing
+        r.flush()
+        r.sync()
+        assert np.all(out.cpu().numpy()[..., 3] == 1.0)     # the running mean of the two frames arrived in `out`
         r.set_frames_in_flight(1)
     finally:
         r.close()
