@@ -1188,7 +1188,8 @@ hipError_t pt_path_resident_blocks(bool nee, bool count, bool few, int device, u
     if (e != hipSuccess) return e;
     // (the query does not know the SGPR side of residency: with 82-96 SGPRs it answers 8 waves per SIMD where the hardware
     //  admits 7, MI355X_MICROARCH.md; the capped plain build is that case)
-    if (PT_PLAIN_SGPRS > 0 && !nee && !count && !few && per_cu > 28) per_cu = 28;
+    constexpr int plain_waves = PT_PLAIN_SGPRS > 0 ? (800 / ((PT_PLAIN_SGPRS + 15) / 16 * 16 + 16) > 8 ? 8 : 800 / ((PT_PLAIN_SGPRS + 15) / 16 * 16 + 16)) : 8;
+    if (PT_PLAIN_SGPRS > 0 && !nee && !count && !few && per_cu > 4 * plain_waves) per_cu = 4 * plain_waves;   // 96 -> 7 per SIMD, 80 -> 8
     if (per_cu < 1) per_cu = 1;
     *blocks = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount * PT_BLOCK / 256u;
     return hipSuccess;
