@@ -112,6 +112,33 @@ def test_ids_cpu_camera_on_cuda_scene(gpu, oracle):
     assert np.array_equal(ids, oracle.primary_ids(sc, cam)[0])
 
 
+def test_ids_exact_distance_ties_go_to_the_first_object_inserted(gpu, oracle):
+    """Scene::intersect keeps the first of two objects at the same distance (strict '<' in insertion order,
+    cpu_pathtracer/include/Scene.h:57-69).  The SoA tests spheres, planes, triangles class by class, so a tie across
+    classes is decided by the object ids: a sphere, a plane and a triangle that the central ray meets at exactly t = 4,
+    inserted in all six orders."""
+    import itertools
+    from path_tracer_amd.scenes import Lambertian, SceneBuilder
+    W = H = 65                                           # generateCameraRay's u = (x + 0.5) / W is 0.5 at x = 32: the axis itself
+    cam = abi.make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 60.0, W, H, abi.CAMERA_CUDA)
+    for order in itertools.permutations(("sphere", "plane", "triangle")):
+        b = SceneBuilder()
+        m = {k: b.material(Lambertian(0.5)) for k in order}
+        for k in order:
+            if k == "sphere": b.addObject(b.Sphere((0, 0, -5), 1.0, m[k]))
+            elif k == "plane": b.addObject(b.Plane((0, 0, -4), (0, 0, 1), m[k]))
+            else: b.addObject(b.Triangle((-1, -1, -4), (1, -1, -4), (0, 1, -4), m[k]))
+        sc = b.flatten()
+        _setup(gpu, sc, cam)
+        ids, mats = gpu.primary_ids()
+        want_ids, want_mats = oracle.primary_ids(sc, cam)
+        assert np.array_equal(ids, want_ids) and np.array_equal(mats, want_mats), order
+        assert ids[32, 32] == 0 and mats[32, 32] == m[order[0]], (order, ids[32, 32])   # the three-way tie: first inserted
+        # the `direct` integrator shades the same winner
+        gpu.render(0, 1, abi.render_params(integrator=abi.INTEGRATOR_DIRECT))
+        assert np.all(gpu.accum()[..., 3] == 1)
+
+
 # --------------------------------------------------------------- T2: direct integrator ---
 def test_direct_matches_oracle(gpu, oracle):
     sc, cam = scenes.cpu_default(320, 180)
