@@ -101,9 +101,10 @@ __device__ DHit scene_hit(const DevSceneD& sc, const DRay& ray) {
 }
 
 // Camera::getRayForPixel (Camera.h:124-142, use_dof == false) or generateCameraRay in double.
+template <int MODEL = -1>   // the camera model as a template argument (the `direct` kernel: only one model's 24 SGPRs of camera stay live in the sample loop), or read from the camera
 __device__ __forceinline__ DRay camera_ray(const DevCamD& k, uint32_t x, uint32_t y, double jx, double jy) {
     const D3 origin = ld3(k.origin);
-    if (k.model == 1u) {
+    if (MODEL < 0 ? k.model == 1u : MODEL == 1) {
         const double u = ((double)x + jx) / (double)(k.width - 1);
         const double v = 1.0 - ((double)y + jy) / (double)(k.height - 1);
         const D3 pixel_loc = ld3(k.top_left) + ld3(k.horizontal) * u + ld3(k.vertical) * v;
@@ -156,10 +157,13 @@ __device__ bool visible(const DevSceneD& sc, D3 from, D3 to) {
 // rays (primary + shadow), hits (primary), nee_samples (light samples drawn), shadow_rays (Scene::isVisible calls).
 // Register budget: left alone the kernel takes 134 VGPRs (3 waves/SIMD); asked for 4 it fits 126 with six spilled and
 // runs 6 % faster (21.8 -> 23.2 Gsamples/s on BASELINE config 1); 5 waves (96 VGPRs, 39 spilled) lose 4 %.
+#ifndef PT_SINCOS
+#define PT_SINCOS 1
+#endif
 #ifndef PT_DIRECT_WAVES
 #define PT_DIRECT_WAVES 4
 #endif
-template <bool COUNT>
+template <bool COUNT, int MODEL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_DIRECT_WAVES))) void pt_direct_kernel(const DevSceneD sc, const DevCamD cam, float4* accum, uint32_t s0,
                                                         uint32_t count, uint32_t seed, uint64_t* counters) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_DIRECT_W
     uint32_t c_hits = 0, c_lights = 0, c_shadow = 0;
     for (uint32_t i = 0; i < count; ++i) {
         const uint32_t key = pt_hash(pt_hash(pt_hash(seed) + p) + (s0 + i));
-        const DRay ray = camera_ray(cam, x, y, duni(pt_draw(key, 0, 0)), duni(pt_draw(key, 0, 1)));
+        const DRay ray = camera_ray<MODEL>(cam, x, y, duni(pt_draw(key, 0, 0)), duni(pt_draw(key, 0, 1)));
         const DHit h = scene_hit(sc, ray);
         if (COUNT) c_hits += h.hit ? 1u : 0u;
         if (!h.hit) { px[0] += 0.2; px[1] += 0.2; px[2] += 0.2; continue; }
@@ -201,8 +205,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_DIRECT_W
             // Sphere::getRandomPoint, ImplicitObject.h:111-125
             const double theta = 2.0 * M_PI * u;
             const double phi = acos(2.0 * v - 1.0);
+#if PT_SINCOS   // one argument reduction and one evaluation per angle: the library's sincos returns its sin's and its cos's bits
+            double sin_theta, cos_theta_, sin_phi, cos_phi;
+            sincos(theta, &sin_theta, &cos_theta_);
+            sincos(phi, &sin_phi, &cos_phi);
+            const D3 dir = d3(cos_theta_ * sin_phi, sin_theta * sin_phi, cos_phi);
+#else
             const double sin_phi = sin(phi);
             const D3 dir = d3(cos(theta) * sin_phi, sin(theta) * sin_phi, cos(phi));
+#endif
             const double* s = sc.sph + 4 * l;
             const D3 lp = d3(s[0], s[1], s[2]) + dir * s[3];
             const D3 light_dir = normalized(lp - hp);
@@ -239,7 +250,14 @@ hipError_t pt_launch_primary_ids(const DevSceneD& sc, const DevCamD& cam, uint32
 hipError_t pt_launch_direct(const DevSceneD& sc, const DevCamD& cam, float4* accum, uint32_t s0, uint32_t count,
                             uint32_t seed, uint64_t* counters, hipStream_t stream) {
     const uint32_t n = cam.width * cam.height;
-    if (counters) hipLaunchKernelGGL(pt_direct_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, stream, sc, cam, accum, s0, count, seed, counters);
-    else hipLaunchKernelGGL(pt_direct_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, stream, sc, cam, accum, s0, count, seed, counters);
+    const dim3 grid((n + 255) / 256), block(256);
+    const bool cpu_cam = cam.model == 1u;
+    if (counters) {
+        if (cpu_cam) hipLaunchKernelGGL((pt_direct_kernel<true, 1>), grid, block, 0, stream, sc, cam, accum, s0, count, seed, counters);
+        else hipLaunchKernelGGL((pt_direct_kernel<true, 0>), grid, block, 0, stream, sc, cam, accum, s0, count, seed, counters);
+    } else {
+        if (cpu_cam) hipLaunchKernelGGL((pt_direct_kernel<false, 1>), grid, block, 0, stream, sc, cam, accum, s0, count, seed, counters);
+        else hipLaunchKernelGGL((pt_direct_kernel<false, 0>), grid, block, 0, stream, sc, cam, accum, s0, count, seed, counters);
+    }
     return hipGetLastError();
 }
