@@ -30,7 +30,10 @@ One JSON line on rank 0.  `roofline` prices the path kernel against the FP32 vec
 FLOPs per launch (event counters x the fixed cost table of SURVEY §8(d)) / time per launch from HIP
 events on the launch stream around the K launches (the overlapped launches fork from and join that
 stream, so this is first start to last end / K, the figure tools/trace_span.py derives from a
-rocprofv3 kernel trace of the same command).  `cpu_baseline` times the CPU oracle
+rocprofv3 kernel trace of the same command).  Beside it the same frames one at a time, without frames in flight:
+`kernel_ms_serial` / `frac_serial` strictly serial (render-ahead off: what rocprofv3 shows per dispatch) and
+`frame_ms_render_ahead` / `frac_render_ahead` as the library runs such a loop by default (the next frame rendered
+ahead, pt_set_render_ahead; same bits).  `cpu_baseline` times the CPU oracle
 (oracle/libpt_oracle.so, OpenMP) on a bounded number of frames of the same workload.
 """
 from __future__ import annotations
@@ -219,19 +222,27 @@ def main() -> int:
         # launch start to last fold pass end, per frame -- the path kernel with its launches overlapping, plus the fold
         # pass of the last launch and the queue latencies between them
         frame_ms = ev0.elapsed_time(ev1) / max(my_steps, 1)
-        serial_ms = None
+        serial_ms = ahead_ms = None
         if serial_probe and flight > 1 and my_steps > 0:
             # the same launches strictly one after another, for comparison with rocprofv3's per-dispatch durations
             r.set_frames_in_flight(1)
             n_serial = min(my_steps, 128)
-            torch.cuda.synchronize()
-            sv0, sv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # (ev2 / ev3 are the combine's)
-            sv0.record()
-            for s0, n in sched[Wm:Wm + n_serial]:
-                r.render(s0, n, params)
-            sv1.record()
-            torch.cuda.synchronize()
-            serial_ms = sv0.elapsed_time(sv1) / n_serial
+            probe = {}
+            for ahead in (False, True):
+                # strictly one launch after the other (what rocprofv3's per-dispatch durations show), and the library's
+                # default for a caller that renders one frame at a time: the next frame rendered ahead (pt_set_render_ahead)
+                r.set_render_ahead(ahead)
+                for s0, n in sched[Wm:Wm + 4]:    # untimed: starts render-ahead (its planes are allocated on first use)
+                    r.render(s0, n, params)
+                torch.cuda.synchronize()
+                sv0, sv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # (ev2 / ev3 are the combine's)
+                sv0.record()
+                for s0, n in sched[Wm + 4:Wm + 4 + n_serial]:
+                    r.render(s0, n, params)
+                sv1.record()
+                torch.cuda.synchronize()
+                probe[ahead] = sv0.elapsed_time(sv1) / max(len(sched[Wm + 4:Wm + 4 + n_serial]), 1)
+            serial_ms, ahead_ms = probe[False], probe[True]
         # the parts of the timed region, from the events (device time on this rank's stream): render = first launch to last
         # fold pass; reduce = the reduce-scatter behind it; display = this rank's resolve + the all-gather of the pictures
         render_s = ev0.elapsed_time(ev1) * 1e-3 if world > 1 else elapsed
@@ -247,7 +258,7 @@ def main() -> int:
         out = {"workload": workload, "scene": scene_name, "width": W, "height": H, "spp_per_step": spp, "max_depth": max_depth,
                "steps": K, "warmup": Wm, "scaling": scaling if world > 1 else "weak", "frames_in_flight": flight,
                "elapsed_s": elapsed, "total_steps": total_steps, "samples_per_step": W * H * spp,
-               "value": total_steps * W * H * spp / elapsed / 1e6, "frame_ms": frame_ms, "launches": launches, "serial_ms": serial_ms,
+               "value": total_steps * W * H * spp / elapsed / 1e6, "frame_ms": frame_ms, "launches": launches, "serial_ms": serial_ms, "ahead_ms": ahead_ms,
                "render_ms": render_s * 1e3, "reduce_ms": reduce_s * 1e3, "display_ms": display_s * 1e3, "my_steps": my_steps,
                "reduce_bytes": (world - 1) * chunk * 16 if world > 1 else 0, "gather_bytes": (world - 1) * chunk * 4 if world > 1 else 0}
         if rank == 0:
@@ -360,6 +371,9 @@ def main() -> int:
         if leg["serial_ms"]:
             d["kernel_ms_serial"] = round(leg["serial_ms"], 5)
             d["frac_serial"] = round(leg["flops_per_frame"] / (leg["serial_ms"] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 5)
+        if leg.get("ahead_ms"):   # one frame at a time with the next one rendered ahead (the library's default without frames in flight)
+            d["frame_ms_render_ahead"] = round(leg["ahead_ms"], 5)
+            d["frac_render_ahead"] = round(leg["flops_per_frame"] / (leg["ahead_ms"] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 5)
         return d
 
     result = None

@@ -315,6 +315,25 @@ uint32_t pt_frames_in_flight(PtContext* ctx);
  * reads a profile. */
 uint64_t pt_path_launches(PtContext* ctx);
 int pt_flush(PtContext* ctx);
+/* Render-ahead, for the loop that launches one frame at a time and shows it before it launches the next (the
+ * reference's own: launchRenderKernel, updateScreen, main.cu:284-303) -- one frame in flight, where a 1280x720 frame
+ * of one sample spends more than half of its launch draining the scene's longest paths.  Once two calls in a row have
+ * continued one another (same parameters, same sample count, equally spaced sample ranges: pt_render or
+ * launchRenderKernel alike), the library also launches the frame that the NEXT call will ask for if the loop goes
+ * on, on a stream of its own into a plane of its own; that launch fills the chip while the current frame's tail
+ * drains and while the host shows it.  If the next call is that frame it only adds the plane to the accumulation
+ * buffer (or applies the running mean's step) and makes the display, as a frame in flight is folded: buffer and
+ * display are the serial loop's bit for bit.  If it is anything else -- another sample range, other parameters, a new
+ * camera or scene -- the plane is dropped and the call renders as usual; render-ahead resumes when two calls
+ * continue one another again.  The cost: one frame of GPU work wasted when the loop stops, and two planes of 16 B
+ * per pixel (allocated when it first happens; a device without room for them renders serially).  On by default for
+ * frames of <= 2^22 pixels and calls of < 4 samples without event counters; off with frames in flight (n > 1), which
+ * do better for callers that can let the library hold frames back.  pt_render_noalloc never renders ahead.
+ * `on` = 0 turns it off (strictly one launch per call, the previous call's kernel ended before the next begins).
+ * pt_render_ahead_stats: frames launched ahead so far, and how many of them a call then used.
+ * No counterpart in the reference. */
+int pt_set_render_ahead(PtContext* ctx, uint32_t on);
+int pt_render_ahead_stats(PtContext* ctx, uint64_t* launched, uint64_t* used);
 /* Resolve the accumulation buffer into the context's display buffer
  * (convertToRGBAKernel / the CPU accumulate+gamma loop).  Asynchronous. */
 int pt_resolve(PtContext* ctx, uint32_t mode);

@@ -19,7 +19,7 @@ SYMBOLS = [
     "pt_set_camera", "pt_resize", "pt_bind_accum", "pt_reset", "pt_render", "pt_resolve", "pt_readback",
     "pt_readback_accum", "pt_history_frames", "pt_readback_history", "pt_upload_accum", "pt_sync", "pt_accum_device_ptr", "pt_display_device_ptr",
     "pt_primary_ids", "pt_counters", "pt_reset_counters", "pt_valu_peak", "pt_make_current",
-    "launchRenderKernel", "pt_builtin_scene", "pt_set_frames_in_flight", "pt_frames_in_flight", "pt_path_launches", "pt_flush",
+    "launchRenderKernel", "pt_builtin_scene", "pt_set_frames_in_flight", "pt_frames_in_flight", "pt_path_launches", "pt_flush", "pt_set_render_ahead", "pt_render_ahead_stats",
     "pt_fly_camera_step", "pt_reduce", "pt_render_noalloc", "pt_path_length_histogram", "pt_resolve_range", "pt_reduce_scatter",
 ]
 
@@ -67,6 +67,8 @@ def lib() -> C.CDLL:
     L.pt_readback_accum.argtypes = [ctx, vp, C.c_size_t]
     L.pt_path_launches.argtypes = [ctx]
     L.pt_path_launches.restype = C.c_uint64
+    L.pt_set_render_ahead.argtypes = [ctx, C.c_uint32]
+    L.pt_render_ahead_stats.argtypes = [ctx, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.pt_history_frames.argtypes = [ctx]
     L.pt_history_frames.restype = C.c_uint32
     L.pt_readback_history.argtypes = [ctx, C.c_uint32, vp, C.c_size_t]

@@ -117,6 +117,19 @@ struct PtContext {
     uint32_t history_frames = 0;       // planes of `history` that hold a picture (frame history_frames-1 is the newest but one)
     // Frames collected for the next overlapped launch (pt_render calls that were accepted but not launched yet)
     struct Pending { uint32_t begin = 0, per_frame = 0, stride = 0, frames = 0; PtRenderParams prm{}; } pending;
+    // Render-ahead (one frame in flight, the reference's loop: launch, show, launch): once two calls in a row have
+    // continued one another -- same parameters, same sample count, equally spaced -- the frame that the NEXT call will
+    // ask for if the loop goes on is launched as well, on one of two streams of its own, into a plane of its own.  If
+    // the next call is that frame, its sums are there (or on their way) and the call only folds them in, exactly as a
+    // frame in flight is folded; if it is anything else the plane is dropped.  The image is the serial loop's bit for
+    // bit; what changes is that frame k + 1 fills the chip while frame k's last long paths drain and the host shows it.
+    bool ahead_on = true;              // pt_set_render_ahead
+    struct Ahead { bool valid = false; uint32_t begin = 0, count = 0, chain = 0; PtRenderParams prm{}; } ahead;
+    struct Last { bool valid = false; uint32_t begin = 0, count = 0, stride = 0, streak = 0; PtRenderParams prm{}; } last;
+    uint32_t ahead_next = 0;           // which of the two render-ahead chains the next such launch takes
+    bool ahead_fold_pending[2] = {false, false};   // per render-ahead chain: a pass on the context's stream still reads its plane
+    bool ahead_fork[2] = {true, true}; // per render-ahead chain: its next launch is ordered behind the context's stream (uploads)
+    uint64_t ahead_launched = 0, ahead_used = 0;   // pt_render_ahead_stats
     uint32_t burst = 0;                // launches since the chains were last joined
     uint64_t path_launches = 0;        // launches of the path kernel since pt_create (pt_path_launches)
     bool burst_displayed = false;      // some launch of the burst asked for a display
@@ -152,6 +165,22 @@ int end_shim_binding(PtContext* ctx) {
     return rc;
 }
 
+// Render-ahead: forget the frame launched ahead (the scene, the camera or the frame size is about to change, or frames
+// in flight take over).  What the context's stream does next is ordered behind the kernels still running ahead.
+// The two chains (streams, planes, ticket counters) render-ahead uses are chains 1 and 2 of the frames in flight, which
+// are never active at the same time: with chain 0 = the context's stream that is the three streams HIP's default of four
+// hardware queues keeps apart (streams of their own shared a queue with the context's stream in a process that had used
+// frames in flight before, and the frame rendered ahead then ran behind the pass it was to overlap).
+constexpr uint32_t AHEAD_CHAIN_0 = 1u;
+int drop_ahead(PtContext* ctx) {
+    for (uint32_t c = AHEAD_CHAIN_0; c < AHEAD_CHAIN_0 + 2u; ++c)
+        if (ctx->chain_done[c]) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->chain_done[c], 0));   // (never recorded: no wait)
+    ctx->ahead.valid = false;
+    ctx->last.valid = false; ctx->last.streak = 0;
+    ctx->ahead_fork[0] = ctx->ahead_fork[1] = true;
+    return PT_OK;
+}
+
 int use(PtContext* ctx) {
     pt_clear_error();
     if (!ctx) return fail(PT_ERR_INVALID, "null context");
@@ -173,6 +202,7 @@ int alloc_frame(PtContext* ctx, uint32_t w, uint32_t h) {
     if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) return fail(PT_ERR_INVALID, "bad frame size %ux%u", w, h);
     if (w == ctx->width && h == ctx->height && ctx->display) return PT_OK;
     if (int rc = join_chains(ctx)) return rc;
+    if (int rc = drop_ahead(ctx)) return rc;
     const size_t npix = (size_t)w * h;
     // the new buffers first, the swap only when both exist: a failed allocation leaves the old frame intact
     float4* accum_new = nullptr;
@@ -303,13 +333,13 @@ int prepare_chains(PtContext* ctx) {
 // synchronises the device, so nothing still uses what is replaced.
 // Returns PT_NO_MEMORY (> 0, internal) when the device has no room: the caller then renders the frames serially.
 constexpr int PT_NO_MEMORY = 1;
-int ensure_chain_buffers(PtContext* ctx, uint32_t chain, uint32_t frames, bool displayed) {
+int ensure_chain_buffers(PtContext* ctx, uint32_t chain, uint32_t frames, bool displayed, bool exact = false) {   // exact: the render-ahead chains hold one frame
     const size_t npix = (size_t)ctx->width * ctx->height;
     if (ctx->knob_fail_chain_alloc) return PT_NO_MEMORY;
     const uint32_t most = frames_per_launch_max(ctx);
     if (ctx->chain_cap[chain] < frames) {
         if (ctx->chain_acc[chain]) { HIP_TRY(hipFree(ctx->chain_acc[chain])); ctx->chain_acc[chain] = nullptr; ctx->chain_cap[chain] = 0; }
-        uint32_t planes = (ctx->own_burst || most < frames) ? frames : most;
+        uint32_t planes = (ctx->own_burst || exact || most < frames) ? frames : most;
         hipError_t e = hipMalloc((void**)&ctx->chain_acc[chain], (size_t)planes * npix * sizeof(float4));
         if (e != hipSuccess && planes > frames) { (void)hipGetLastError(); planes = frames; e = hipMalloc((void**)&ctx->chain_acc[chain], (size_t)planes * npix * sizeof(float4)); }
         if (e != hipSuccess) { (void)hipGetLastError(); ctx->chain_acc[chain] = nullptr; return PT_NO_MEMORY; }
@@ -387,6 +417,7 @@ bool wants_parts(const PtContext* ctx, uint32_t sample_count, const PtRenderPara
 }
 
 int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm, float4* into = nullptr);
+int launch_serial(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm);
 
 // With frames in flight the launches join the open burst; without, the call is a burst of its own on
 // `burst_chains` chains, folded before it returns, and a fused display is made from the folded sums.  The
@@ -399,6 +430,7 @@ int render_in_parts(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count
     const uint32_t user_flight = ctx->flight;
     PtRenderParams sub = *prm;
     if (!pipelined) {
+        if (int rc = drop_ahead(ctx)) return rc;   // the burst takes the chains that render-ahead uses
         ctx->flight = ctx->burst_chains;
         ctx->own_burst = true;
         sub.fused_rgba8 = 0;
@@ -472,11 +504,44 @@ constexpr uint32_t PREFETCH_PAIRS_PER_LANE = 8, PREFETCH_SMALL_SCENE_COST = 800;
 //  * otherwise (frames == 1): a serial launch on the context's stream that adds to the accumulation buffer itself.
 //    `into` != nullptr is pt_render_noalloc's launch: into the caller's buffer, with the ticket counters in the device's
 //    static scratch array; nothing on that path allocates, queries or creates anything.
+//  * ahead_chain >= 0 (frames == 1, not pipelined): the render-ahead launch of a frame nobody has asked for yet, on that
+//    chain's stream into that chain's plane, like a pipelined launch but outside the burst's book-keeping: no fold pass
+//    is scheduled (the call that turns out to want the frame enqueues it, launch_path), chain_done[chain] marks its end.
 int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uint32_t frames, uint32_t frame_stride,
-               const PtRenderParams* prm, float4* into, bool pipelined) {
+               const PtRenderParams* prm, float4* into, bool pipelined, int ahead_chain = -1) {
     const bool noalloc = into != nullptr;
+    const bool ahead = ahead_chain >= 0;
+    const bool overlapped = pipelined || ahead;                       // shares the chip with another launch
+    const uint32_t overlap = pipelined ? ctx->flight : (ahead ? 2u : 1u);
     uint32_t chain = 0;
     hipStream_t stream = ctx->stream;
+    if (ahead) {
+        chain = (uint32_t)ahead_chain;
+        if (!ctx->fork_event) HIP_TRY(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+        // Streams: no more than three with work on them, the number HIP's default of four hardware queues keeps apart (a
+        // fourth shares a queue with one of them, and a frame rendered ahead on the queue of the context's stream runs
+        // behind the pass it was to overlap: 0.25 ms per frame instead of 0.14).  A context on its own stream uses chains 1
+        // and 2; one that runs on the caller's stream leaves its own stream idle, and that takes chain 2's place.
+        const bool borrow_own = chain == AHEAD_CHAIN_0 + 1u && ctx->own_stream && ctx->stream != ctx->own_stream;
+        if (!borrow_own && !ctx->chain_stream[chain]) HIP_TRY(hipStreamCreateWithFlags(&ctx->chain_stream[chain], hipStreamNonBlocking));
+        if (!ctx->chain_done[chain]) HIP_TRY(hipEventCreateWithFlags(&ctx->chain_done[chain], hipEventDisableTiming));
+        stream = borrow_own ? ctx->own_stream : ctx->chain_stream[chain];
+        // the first such launch after a change of scene, camera or frame goes behind what the context's stream holds (the
+        // uploads among it); the later ones must NOT wait for that stream -- it holds the previous frame's fold pass, which
+        // waits for the previous frame's kernel, the very kernel this one is to overlap
+        if (!ctx->fold_done[chain]) HIP_TRY(hipEventCreateWithFlags(&ctx->fold_done[chain], hipEventDisableTiming));
+        // the plane is written again: not before the pass that took the chain's previous frame out of it has run
+        if (ctx->ahead_fold_pending[chain - AHEAD_CHAIN_0]) {
+            HIP_TRY(hipStreamWaitEvent(stream, ctx->fold_done[chain], 0));
+            ctx->ahead_fold_pending[chain - AHEAD_CHAIN_0] = false;
+        }
+        if (ctx->ahead_fork[chain - AHEAD_CHAIN_0]) {
+            HIP_TRY(hipEventRecord(ctx->fork_event, ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(stream, ctx->fork_event, 0));
+            ctx->ahead_fork[chain - AHEAD_CHAIN_0] = false;
+        }
+        if (int rc = ensure_chain_buffers(ctx, chain, 1u, false, true)) return rc;   // (PT_NO_MEMORY: the caller simply does not render ahead)
+    }
     if (pipelined) {
         if (ctx->burst == 0) {
             if (int rc = prepare_chains(ctx)) return rc;
@@ -493,9 +558,9 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     PathArgs a{};
     // A launch that overlaps others writes its own sums (sum_r, sum_g, sum_b, count) whole into its chain's buffer;
     // the fold pass behind it adds them to the accumulation buffer and makes the display (pt_fold_kernel).
-    a.accum = noalloc ? into : (pipelined ? ctx->chain_acc[chain] : ctx->accum);
-    a.overwrite = pipelined ? 1u : 0u;
-    a.rgba = (prm->fused_rgba8 && !pipelined) ? (uint32_t*)ctx->display : nullptr;
+    a.accum = noalloc ? into : (overlapped ? ctx->chain_acc[chain] : ctx->accum);
+    a.overwrite = overlapped ? 1u : 0u;
+    a.rgba = (prm->fused_rgba8 && !overlapped) ? (uint32_t*)ctx->display : nullptr;
     if (a.rgba) ctx->history_frames = 0;  // (the display no longer continues the history planes)
     a.counters = (prm->flags & PT_FLAG_COUNTERS) ? ctx->counters : nullptr;
     a.hist = a.counters ? ctx->counters + 12 : nullptr;
@@ -531,7 +596,7 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
         a.few_max = few > tune::FEW_MAX_CAP ? tune::FEW_MAX_CAP : few;
         // (serial launches: 720p, 1 spp +15 % with it; 4K, 16 spp, 340 samples per resident lane, -3 %)
         const uint64_t per_lane = ((uint64_t)ctx->width * ctx->height * sample_count * frames) / ((uint64_t)ctx->compute_units * tune::LANES_PER_CU_AT_6_WAVES);
-        if ((pipelined || per_lane >= tune::FEW_LONG_LAUNCH_SAMPLES_PER_LANE) && a.few_max < tune::FEW_MIN_THRESHOLD_WHEN_OVERLAPPED) a.few_max = 0u;
+        if ((overlapped || per_lane >= tune::FEW_LONG_LAUNCH_SAMPLES_PER_LANE) && a.few_max < tune::FEW_MIN_THRESHOLD_WHEN_OVERLAPPED) a.few_max = 0u;
         if (ctx->knob_few_max >= 0) a.few_max = (uint32_t)ctx->knob_few_max;
     }
     const bool few = a.few_max > 0u;
@@ -552,12 +617,12 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     //  with small grids: `random4096` at 720p, 8 x 259 blocks 168 Msamples/s, 4 x 518 226.  A sample of a
     //  large scene therefore counts as many: its brute-force cost relative to the Cornell box's.)
     uint32_t cap = resident;
-    if (pipelined) {
+    if (overlapped) {
         const uint64_t weight = serial_cost > tune::GRID_COST_OF_A_CORNELL_SAMPLE ? serial_cost / tune::GRID_COST_OF_A_CORNELL_SAMPLE : 1u;
         const uint64_t by_work = ((uint64_t)ctx->width * ctx->height * sample_count * frames * weight) / (256u * tune::GRID_SAMPLES_PER_LANE);
         // (the factor is against 6 waves/SIMD: a build that fits 7 has the same optimum in blocks)
         const uint32_t six = ctx->compute_units * 6u;
-        const uint32_t by_fill = ((resident < six ? resident : six) * tune::GRID_FILL_NUM) / (tune::GRID_FILL_DEN * ctx->flight);
+        const uint32_t by_fill = ((resident < six ? resident : six) * tune::GRID_FILL_NUM) / (tune::GRID_FILL_DEN * overlap);
         const uint32_t want = by_work > by_fill ? (by_work > resident ? resident : (uint32_t)by_work) : by_fill;
         if (want < cap) cap = want;
         // (a launch of many frames: a quarter more waves than are resident -- the surplus starts as slots come free and
@@ -593,7 +658,7 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     // (launches that overlap others lose less to a withheld pixel -- another launch's lanes fill in: 720p, 16 spp, 8 in
     //  flight +3 % with it, `random4096` -7 %)
     a.prefetch_pixels = ((uint64_t)ctx->width * ctx->height * frames >= (uint64_t)cap * 256u * tune::PREFETCH_PAIRS_PER_LANE ||
-                         (pipelined && sample_count > 1u && serial_cost <= tune::PREFETCH_SMALL_SCENE_COST)) ? 1u : 0u;
+                         (overlapped && sample_count > 1u && serial_cost <= tune::PREFETCH_SMALL_SCENE_COST)) ? 1u : 0u;
     if (ctx->knob_regen_min >= 0) a.regen_min = (uint32_t)ctx->knob_regen_min;
     if (ctx->knob_idle_min >= 0) a.idle_min = (uint32_t)ctx->knob_idle_min;
     if (ctx->knob_prefetch >= 0) a.prefetch_pixels = (uint32_t)ctx->knob_prefetch;
@@ -615,7 +680,7 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
         a.next_counter = ctx->scratch + WORK_SET_WORDS;
         HIP_TRY(hipMemsetAsync(a.work_counter, 0, WORK_SET_WORDS * sizeof(uint32_t), stream));
     }
-    const char* trace_file = (ctx->knob_trace.empty() || noalloc) ? nullptr : ctx->knob_trace.c_str();  // kernel-timeline experiments (tools/gpu_trace.py)
+    const char* trace_file = (ctx->knob_trace.empty() || noalloc || ahead) ? nullptr : ctx->knob_trace.c_str();  // kernel-timeline experiments (tools/gpu_trace.py)
     if (trace_file) {
         const size_t waves = (size_t)blocks * 4u;
         if (ctx->trace_waves < waves) {
@@ -627,6 +692,12 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
         a.trace = ctx->trace;
     } else a.trace = nullptr;
     PROF(ctx, 1, pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, few, blocks, stream));
+    if (ahead) {   // counted as a launch when a call takes the frame (launch_path); nothing else of the context's state moves
+        HIP_TRY(hipEventRecord(ctx->chain_done[chain], stream));
+        ctx->work_parity[chain] ^= 1u;
+        ctx->ahead_launched++;
+        return PT_OK;
+    }
     ctx->path_launches++;
     if (pipelined) {
         ctx->chain_frames[chain] = frames;
@@ -665,6 +736,52 @@ int launch_pending(PtContext* ctx, bool joining) {
     return PT_OK;
 }
 
+// A serial launch (one frame in flight) with render-ahead around it (PtContext::ahead).  Render-ahead is for the frame
+// loop that the serial launch serves worst: frames of <= 2^22 pixels (larger ones give every lane enough pixels to stay
+// busy to the end), a few samples per call, no event counters.  It starts once two calls in a row have continued one
+// another and stops with the first that does not.
+int launch_serial(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, const PtRenderParams* prm) {
+    const uint32_t npix = ctx->width * ctx->height;
+    const bool eligible = ctx->ahead_on && !ctx->own_burst && ctx->knob_trace.empty() && !ctx->knob_fail_chain_alloc &&
+                          sample_count < 4u && (uint64_t)npix <= (1ull << 22) && !(prm->flags & PT_FLAG_COUNTERS);
+    PtContext::Ahead& ah = ctx->ahead;
+    PtContext::Last& last = ctx->last;
+    bool taken = false;
+    if (ah.valid) {
+        ah.valid = false;   // one way or the other, the plane is spoken for
+        if (eligible && ah.begin == sample_begin && ah.count == sample_count && memcmp(&ah.prm, prm, sizeof(PtRenderParams)) == 0) {
+            // the frame was launched ahead: behind its kernel, the pass that a frame in flight gets -- acc += plane (or the
+            // running mean's step) and the frame's display -- on the context's stream
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->chain_done[ah.chain], 0));
+            HIP_TRY(pt_launch_fold(ctx->accum, ctx->chain_acc[ah.chain], npix, 1u, prm->fused_rgba8 ? (uint32_t*)ctx->display : nullptr, nullptr, npix,
+                                   prm->acc_mode, sample_begin, sample_count, ctx->stream));
+            HIP_TRY(hipEventRecord(ctx->fold_done[ah.chain], ctx->stream));
+            ctx->ahead_fold_pending[ah.chain - AHEAD_CHAIN_0] = true;
+            ctx->path_launches++;
+            ctx->ahead_used++;
+            ctx->last_acc_mode = prm->acc_mode;
+            if (prm->fused_rgba8) { ctx->display_bytes = (size_t)npix * 4; ctx->history_frames = 0; }
+            taken = true;
+        }
+    }
+    if (!taken)
+        if (int rc = launch_now(ctx, sample_begin, sample_count, 1u, sample_count, prm, nullptr, false)) return rc;
+    // does this call continue the one before it?
+    const bool continues = last.valid && last.count == sample_count && memcmp(&last.prm, prm, sizeof(PtRenderParams)) == 0 &&
+                           sample_begin >= last.begin + last.count && (last.streak == 0u || sample_begin - last.begin == last.stride);
+    if (continues) { last.stride = sample_begin - last.begin; last.streak++; }
+    else { last.streak = 0u; last.stride = 0u; last.count = sample_count; last.prm = *prm; }
+    last.valid = true; last.begin = sample_begin;
+    if (eligible && last.streak >= 1u && (uint64_t)sample_begin + last.stride + sample_count <= 0xFFFFFFFFull) {
+        const uint32_t chain = AHEAD_CHAIN_0 + (ctx->ahead_next & 1u);
+        const int rc = launch_now(ctx, sample_begin + last.stride, sample_count, 1u, sample_count, prm, nullptr, false, (int)chain);
+        if (rc == PT_OK) { ah.valid = true; ah.begin = sample_begin + last.stride; ah.count = sample_count; ah.chain = chain; ah.prm = *prm; ctx->ahead_next++; }
+        else if (rc != PT_NO_MEMORY) return rc;
+        else ctx->ahead_on = false;   // no room for a plane: this context renders serially from here on
+    }
+    return PT_OK;
+}
+
 // One pt_render call (or one part of a large one).  With frames in flight the call is a FRAME of the next overlapped
 // launch: consecutive calls with the same parameters and sample count, each continuing where the one before it ended
 // (the reference's frame loop, main.cu:284-303, is exactly that), are collected and leave as one launch when
@@ -675,7 +792,7 @@ int launch_path(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, co
     if (into) return launch_now(ctx, sample_begin, sample_count, 1u, sample_count, prm, into, false);  // (pt_render_noalloc has checked that no burst is open)
     if (!(ctx->flight > 1 && can_overlap(ctx, prm))) {
         if (int rc = join_chains(ctx)) return rc;
-        return launch_now(ctx, sample_begin, sample_count, 1u, sample_count, prm, nullptr, false);
+        return launch_serial(ctx, sample_begin, sample_count, prm);
     }
     // The frames of a launch are equally long and equally far apart: the second frame fixes the distance (the sample
     // count for one process; a multiple of it when the samples of every step are divided among GPUs, each rank
@@ -727,6 +844,7 @@ int pt_create(int device_id, PtContext** out) {
     if (const char* e = getenv("PT_AMD_FEW_MAX")) ctx->knob_few_max = atoi(e);
     if (const char* e = getenv("PT_AMD_MAX_BLOCKS")) ctx->knob_max_blocks = atoi(e);
     if (const char* e = getenv("PT_AMD_TRACE")) ctx->knob_trace = e;
+    if (const char* e = getenv("PT_AMD_RENDER_AHEAD")) ctx->ahead_on = atoi(e) != 0;   // (pt_set_render_ahead's default, for A/B runs)
     if (const char* e = getenv("PT_AMD_CHUNK")) ctx->knob_chunk = atoi(e);
     if (const char* e = getenv("PT_AMD_REGEN_MIN")) ctx->knob_regen_min = atoi(e);
     if (const char* e = getenv("PT_AMD_IDLE_MIN")) ctx->knob_idle_min = atoi(e);
@@ -804,6 +922,7 @@ int pt_use_own_stream(PtContext* ctx) {
 int pt_upload_scene(PtContext* ctx, const PtSceneSoA* s) {
     if (int rc = use(ctx)) return rc;
     if (int rc = join_chains(ctx)) return rc;  // the stream is synchronised below, before the old scene is freed
+    if (int rc = drop_ahead(ctx)) return rc;
     if (!s) return fail(PT_ERR_INVALID, "scene is null");
     const uint32_t ns = s->num_spheres, np = s->num_planes, nt = s->num_triangles, nm = s->num_materials;
     if (ns > PT_MAX_SPHERES || np > PT_MAX_PLANES || nt > PT_MAX_TRIANGLES || nm > PT_MAX_MATERIALS)
@@ -1001,6 +1120,7 @@ int pt_set_camera(PtContext* ctx, const PtCamera* c) {
     if (!(c->fov_deg > 0.0 && c->fov_deg < 180.0)) return fail(PT_ERR_INVALID, "fov must be in (0,180) degrees");
     if (c->use_dof && !(c->aperture >= 0.0 && c->focus_dist > 0.0)) return fail(PT_ERR_INVALID, "depth of field needs aperture >= 0 and focus_dist > 0");
     if (int rc = launch_pending(ctx)) return rc;  // frames held back for the next overlapped launch belong to the old camera
+    if (int rc = drop_ahead(ctx)) return rc;      // ... and so does a frame rendered ahead
     if (int rc = alloc_frame(ctx, c->width, c->height)) return rc;
 
     // ---- Camera_t::initialize (Camera.cu:3-23), float; initializeGPUData (raytracer_kernel.cu:308-321)
@@ -1245,6 +1365,21 @@ int pt_set_frames_in_flight(PtContext* ctx, uint32_t n) {
     // run at 10.3), so the request is granted up to what GPU_MAX_HW_QUEUES leaves room for: 3 with the default,
     // queues - 4 beyond it.  pt_frames_in_flight() tells the caller what it got.
     ctx->flight = n < ctx->burst_chains ? n : ctx->burst_chains;
+    if (ctx->flight > 1u) return drop_ahead(ctx);   // frames in flight take over from render-ahead
+    return PT_OK;
+}
+
+int pt_set_render_ahead(PtContext* ctx, uint32_t on) {
+    if (int rc = use(ctx)) return rc;
+    ctx->ahead_on = on != 0u;
+    return on ? PT_OK : drop_ahead(ctx);
+}
+
+int pt_render_ahead_stats(PtContext* ctx, uint64_t* launched, uint64_t* used) {
+    pt_clear_error();
+    if (!ctx) return fail(PT_ERR_INVALID, "null context");
+    if (launched) *launched = ctx->ahead_launched;
+    if (used) *used = ctx->ahead_used;
     return PT_OK;
 }
 

@@ -147,6 +147,17 @@ class Renderer:
         """Launches of the path kernel made so far (pt_path_launches)."""
         return int(self._L.pt_path_launches(self._ctx))
 
+    def set_render_ahead(self, on: bool):
+        """Render-ahead of the one-frame-at-a-time loop (pt_set_render_ahead): on by default."""
+        check(self._L.pt_set_render_ahead(self._ctx, 1 if on else 0))
+
+    def render_ahead_stats(self):
+        """(frames launched ahead, frames a call then used) -- pt_render_ahead_stats."""
+        import ctypes as C
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(self._L.pt_render_ahead_stats(self._ctx, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def history_frames(self) -> int:
         """Frames in flight: how many displays older than the newest the last fold pass left (pt_history_frames)."""
         return int(self._L.pt_history_frames(self._ctx))

@@ -346,3 +346,66 @@ def test_random_mixes_of_sum_and_mean_frames_equal_the_serial_loop(gpu):
         assert np.isfinite(want).all()
         assert np.array_equal(got, want), seed
         assert np.array_equal(got_rgba, want_rgba), seed
+
+
+def test_render_ahead_gives_the_serial_loops_bits(gpu):
+    """Render-ahead (pt_set_render_ahead, on by default with one frame in flight): the frame the loop will ask for next is
+    launched before it is asked for.  Buffer and display after every frame are those of strictly serial launches, for
+    sums and for the running mean, through pt_render and through launchRenderKernel, whether the host reads between
+    the frames or not; a call that does not continue the loop drops the plane and renders as usual."""
+    import torch
+    sc, cam = scenes.cuda_default(192, 108)
+    for p in (abi.render_params(fused_rgba8=1), abi.render_params(acc_mode=abi.ACC_RUNNING_MEAN, fused_rgba8=1), abi.render_params(max_depth=8)):
+        spp = 1 if p.acc_mode == abi.ACC_RUNNING_MEAN else 2
+        # what the loop asks for: 6 frames in a row, a jump back, 4 more, another frame size of samples, 3 more
+        calls = [(k * spp, spp) for k in range(6)] + [(2 * spp, spp)] + [((7 + k) * spp, spp) for k in range(4)]
+        if spp == 2: calls += [(40, 1), (41, 1), (42, 1), (43, 1)]
+        gpu.set_render_ahead(False)
+        _setup(gpu, sc, cam)
+        want = []
+        for s0, n in calls:
+            gpu.render(s0, n, p)
+            want.append((gpu.accum(), gpu.readback(abi.RESOLVE_RGBA8_CUDA) if p.fused_rgba8 else None))
+        for read_between in (True, False):
+            gpu.set_render_ahead(True)
+            _setup(gpu, sc, cam)
+            launched0, used0 = gpu.render_ahead_stats()
+            launches0 = gpu.path_launches()
+            for k, (s0, n) in enumerate(calls):
+                gpu.render(s0, n, p)
+                if read_between:
+                    assert np.array_equal(gpu.accum(), want[k][0]), (k, s0)
+                    if p.fused_rgba8: assert np.array_equal(gpu.readback(abi.RESOLVE_RGBA8_CUDA), want[k][1]), (k, s0)
+            assert np.array_equal(gpu.accum(), want[-1][0])
+            if p.fused_rgba8: assert np.array_equal(gpu.readback(abi.RESOLVE_RGBA8_CUDA), want[-1][1])
+            launched, used = gpu.render_ahead_stats()
+            assert gpu.path_launches() - launches0 == len(calls)          # one launch counted per frame, as before
+            assert used - used0 >= 4 and launched - launched0 > used - used0   # frames came from planes; the jumps wasted theirs
+    # a camera change drops the frame rendered ahead for the old camera
+    gpu.set_render_ahead(True)
+    p = abi.render_params(fused_rgba8=1)
+    _setup(gpu, sc, cam)
+    for k in range(4): gpu.render(k, 1, p)
+    cam2 = abi.make_camera((0.3, 1.0, 3.2), (0, 1, 0), (0, 1, 0), 40.0, 192, 108, abi.CAMERA_CUDA)
+    gpu.set_camera(cam2); gpu.reset()
+    for k in range(4, 8): gpu.render(k, 1, p)          # sample 4 was rendered ahead with the old camera: must not be used
+    got = gpu.accum()
+    gpu.set_render_ahead(False)
+    gpu.set_camera(cam2); gpu.reset()
+    for k in range(4, 8): gpu.render(k, 1, p)
+    assert np.array_equal(got, gpu.accum())
+    # launchRenderKernel, the reference's loop: launch, read `output`, launch
+    _setup(gpu, sc, cam)
+    out_a = torch.zeros((108, 192, 4), device="cuda", dtype=torch.float32)
+    out_b = torch.zeros_like(out_a)
+    torch.cuda.synchronize()
+    for out, on in ((out_a, False), (out_b, True)):
+        gpu.set_render_ahead(on)
+        seen = []
+        for f in range(7):
+            gpu.launch_render_kernel(out.data_ptr(), f)
+            gpu.sync()
+            seen.append(out.cpu().numpy().copy())
+        if on: assert all(np.array_equal(x, y) for x, y in zip(seen, ref_seen))
+        else: ref_seen = seen
+    gpu.set_render_ahead(True)

@@ -1208,10 +1208,11 @@ def test_pt_reduce_on_a_one_rank_communicator(gpu):
         assert gpu.reduce_scatter(comm.value, 0, 1) == (0, 160 * 90)
         assert np.array_equal(gpu.accum(), after)
         out = torch.zeros(160 * 90, device="cuda", dtype=torch.int32)
+        part = torch.zeros(1000, device="cuda", dtype=torch.int32)
+        torch.cuda.synchronize()                # (torch clears them on its own stream; the context's is not ordered with it)
         gpu.resolve_range(abi.RESOLVE_RGBA8_CUDA, 0, 160 * 90, out)
         gpu.sync()
         assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(90, 160), gpu.resolve_to_host(abi.RESOLVE_RGBA8_CUDA))
-        part = torch.zeros(1000, device="cuda", dtype=torch.int32)
         gpu.resolve_range(abi.RESOLVE_RGBA8_CUDA, 4321, 1000, part)
         gpu.sync()
         assert np.array_equal(part.cpu().numpy().view(np.uint32), gpu.readback(abi.RESOLVE_RGBA8_CUDA).reshape(-1)[4321:5321])
