@@ -210,7 +210,9 @@ int pt_set_camera(PtContext* ctx, const PtCamera* camera);
 int pt_resize(PtContext* ctx, uint32_t width, uint32_t height);
 /* Render into a caller-owned device buffer of width*height float4 instead of
  * the context's own (NULL unbinds).  This is how a torch tensor becomes the
- * accumulation buffer for the RCCL reduce. */
+ * accumulation buffer for the RCCL reduce.  Work on the buffer is asynchronous
+ * like everything else: unbinding does not wait for it, so pt_sync() (or a wait
+ * on the context's stream) comes before the caller frees or reuses the memory. */
 int pt_bind_accum(PtContext* ctx, void* dev_float4);
 /* Zero the accumulation buffer and the sample count — the CPU app's reset on
  * camera movement (cpu_pathtracer/src/main.cpp:201-205). */

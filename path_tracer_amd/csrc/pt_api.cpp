@@ -127,6 +127,7 @@ struct PtContext {
     struct Ahead { bool valid = false; uint32_t begin = 0, count = 0, chain = 0; PtRenderParams prm{}; } ahead;
     struct Last { bool valid = false; uint32_t begin = 0, count = 0, stride = 0, streak = 0; PtRenderParams prm{}; } last;
     uint32_t ahead_next = 0;           // which of the two render-ahead chains the next such launch takes
+    bool ahead_launched_on[2] = {false, false};    // per render-ahead chain: chain_done holds the end of a launch ahead
     bool ahead_fold_pending[2] = {false, false};   // per render-ahead chain: a pass on the context's stream still reads its plane
     bool ahead_fork[2] = {true, true}; // per render-ahead chain: its next launch is ordered behind the context's stream (uploads)
     uint64_t ahead_launched = 0, ahead_used = 0;   // pt_render_ahead_stats
@@ -266,6 +267,7 @@ int join_chains(PtContext* ctx) {
     if (ctx->chain_stream[last] != ctx->stream) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->fold_done[last], 0));  // (chain 0 is the context's stream itself)
     ctx->burst = 0;
     ctx->folds_queued = 0;
+    ctx->ahead_fork[0] = ctx->ahead_fork[1] = true;   // render-ahead shares chains 1 and 2: its next launches go behind the fold passes
     if (ctx->burst_displayed && !ctx->display_current) {
         // some launch of the burst asked for a display and a later one did not: redo it from the sums
         HIP_TRY(pt_launch_resolve(ctx->accum, ctx->display, ctx->width * ctx->height, ctx->last_acc_mode, PT_RESOLVE_RGBA8_CUDA, ctx->stream));
@@ -530,6 +532,10 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
         // uploads among it); the later ones must NOT wait for that stream -- it holds the previous frame's fold pass, which
         // waits for the previous frame's kernel, the very kernel this one is to overlap
         if (!ctx->fold_done[chain]) HIP_TRY(hipEventCreateWithFlags(&ctx->fold_done[chain], hipEventDisableTiming));
+        // behind the chain's previous launch ahead, whatever stream that ran on (a frame that was dropped has no pass behind
+        // it to wait for, and the context may have changed streams since: two launches on one plane and one set of ticket
+        // counters must not overlap)
+        if (ctx->ahead_launched_on[chain - AHEAD_CHAIN_0]) HIP_TRY(hipStreamWaitEvent(stream, ctx->chain_done[chain], 0));
         // the plane is written again: not before the pass that took the chain's previous frame out of it has run
         if (ctx->ahead_fold_pending[chain - AHEAD_CHAIN_0]) {
             HIP_TRY(hipStreamWaitEvent(stream, ctx->fold_done[chain], 0));
@@ -694,6 +700,7 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     PROF(ctx, 1, pt_launch_path(ctx->sf, ctx->cf, a, nee, cnt, few, blocks, stream));
     if (ahead) {   // counted as a launch when a call takes the frame (launch_path); nothing else of the context's state moves
         HIP_TRY(hipEventRecord(ctx->chain_done[chain], stream));
+        ctx->ahead_launched_on[chain - AHEAD_CHAIN_0] = true;
         ctx->work_parity[chain] ^= 1u;
         ctx->ahead_launched++;
         return PT_OK;

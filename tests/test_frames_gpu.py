@@ -409,3 +409,91 @@ def test_render_ahead_gives_the_serial_loops_bits(gpu):
         if on: assert all(np.array_equal(x, y) for x, y in zip(seen, ref_seen))
         else: ref_seen = seen
     gpu.set_render_ahead(True)
+
+
+def test_render_ahead_under_random_host_behaviour():
+    """Two contexts get the same random sequence of calls -- frames that continue, repeat or jump, 1 to 3 samples, sums and
+    running means, light sampling on and off, resets, reads, checkpoints put back, camera moves, resizes, scene changes,
+    bound tensors, stream switches, episodes of frames in flight -- one with render-ahead, one without: after every call
+    that reads, buffer and display are equal bit for bit."""
+    import torch
+    from path_tracer_amd.renderer import Renderer
+    torch.cuda.set_stream(torch.cuda.Stream())
+    a, b = Renderer(0), Renderer(0)
+    try:
+        b.set_render_ahead(False)
+        launched0 = a.render_ahead_stats()
+        import os
+        for seed in range(5, 5 + int(os.environ.get("PT_AHEAD_FUZZ_SEEDS", "2"))):   # (more seeds for a long run by hand)
+            rng = np.random.default_rng(20261111 + seed)
+            size = (96, 54)
+            scene_name = "cuda_default"
+            bound = [None, None]
+            def setup():
+                for r in (a, b):
+                    if r._bound is not None: r.sync(); r.unbind()      # (the previous seed's tensor is about to be freed)
+                    sc, cam = scenes.builtin(scene_name, *size)
+                    r.set_scene(sc); r.set_camera(cam); r.reset()
+            setup()
+            prm = abi.render_params(fused_rgba8=1)
+            s, n = 0, 1
+            log = []
+            for step in range(260):
+                k = int(rng.integers(0, 100))
+                log.append((step, k, s, n, prm.acc_mode, prm.fused_rgba8, prm.flags, prm.max_depth, size, scene_name, bound[0] is not None))
+                if k < 62:                       # the loop goes on
+                    for r in (a, b): r.render(s, n, prm)
+                    s += n if prm.acc_mode == abi.ACC_SUM else 1
+                elif k < 66:                     # jump or repeat
+                    s = int(rng.integers(0, 50))
+                elif k < 70:                     # other parameters
+                    mean = rng.integers(0, 3) == 0
+                    n = 1 if mean else int(rng.integers(1, 4))
+                    prm = abi.render_params(fused_rgba8=int(rng.integers(0, 2)), acc_mode=abi.ACC_RUNNING_MEAN if mean else abi.ACC_SUM,
+                                            flags=abi.FLAG_NEE_MIS if rng.integers(0, 3) == 0 else 0, max_depth=int(rng.choice([2, 8, 50])))
+                    if mean:
+                        for r in (a, b): r.reset()
+                        s = 0
+                elif k < 74:
+                    for r in (a, b): r.reset()
+                elif k < 78:                     # camera move (same size) or resize
+                    if rng.integers(0, 2): size = [(96, 54), (120, 40), (64, 64)][int(rng.integers(0, 3))]
+                    eye = (float(rng.uniform(-0.5, 0.5)), 1.0 + float(rng.uniform(-0.3, 0.3)), 3.0)
+                    cam = abi.make_camera(eye, (0, 1, 0), (0, 1, 0), 45.0, size[0], size[1], abi.CAMERA_CUDA)
+                    for i, r in enumerate((a, b)):
+                        if bound[i] is not None: r.sync(); r.unbind(); bound[i] = None     # (work on a caller's buffer is asynchronous: wait before it is freed)
+                        r.set_camera(cam); r.reset()
+                elif k < 80:
+                    scene_name = ["cuda_default", "glass_stress"][int(rng.integers(0, 2))]
+                    for r in (a, b):
+                        sc, _ = scenes.builtin(scene_name, *size); r.set_scene(sc); r.reset()
+                elif k < 83:                     # a caller-owned buffer, or back to the context's own
+                    for i, r in enumerate((a, b)):
+                        if bound[i] is None:
+                            t = torch.zeros((size[1], size[0], 4), device="cuda", dtype=torch.float32); torch.cuda.synchronize()
+                            r.bind_tensor(t); bound[i] = t
+                        else:
+                            r.sync(); r.unbind(); bound[i] = None; r.reset()
+                elif k < 86:
+                    for r in (a, b): (r.use_torch_stream if rng.integers(0, 2) else r.use_own_stream)()
+                elif k < 89:                     # an episode of frames in flight
+                    for r in (a, b): r.set_frames_in_flight(2)
+                    for _ in range(int(rng.integers(1, 6))):
+                        for r in (a, b): r.render(s, n, prm)
+                        s += n if prm.acc_mode == abi.ACC_SUM else 1
+                    for r in (a, b): r.set_frames_in_flight(1)
+                elif k < 92:                     # checkpoint out and in again
+                    for r in (a, b): r.upload_accum(r.accum())
+                else:                            # the host looks
+                    ga, gb = a.accum(), b.accum()
+                    if not np.array_equal(ga, gb) and os.path.isdir("gpurun_out"):      # (the steps that led here, for tools/ahead_replay.py)
+                        with open("gpurun_out/ahead_fuzz_fail.txt", "w") as f:
+                            f.write("\n".join(repr(x) for x in log[-60:]) + f"\nseed {seed} step {step} w: {np.unique(ga[..., 3])} vs {np.unique(gb[..., 3])}\n")
+                    assert np.array_equal(ga, gb), (seed, step)
+                    if prm.fused_rgba8 and ga[..., 3].max() > 0:
+                        assert np.array_equal(a.resolve_to_host(abi.RESOLVE_RGBA8_CUDA), b.resolve_to_host(abi.RESOLVE_RGBA8_CUDA)), (seed, step)
+            assert np.array_equal(a.accum(), b.accum()), seed
+        launched, used = a.render_ahead_stats()
+        assert used > 100 and launched > used and b.render_ahead_stats() == (0, 0)
+    finally:
+        a.close(); b.close()

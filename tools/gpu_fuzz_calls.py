@@ -8,6 +8,7 @@ from path_tracer_amd import abi, scenes
 from path_tracer_amd.renderer import Renderer
 os.environ["PT_AMD_CHUNK"] = "0"
 ref = Renderer(0)
+ref.set_render_ahead(False)   # the reference side: strictly one launch per call
 del os.environ["PT_AMD_CHUNK"]
 r = Renderer(0)
 one = Renderer(0)   # the library's defaults with one frame in flight
