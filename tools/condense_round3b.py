@@ -15,8 +15,10 @@ for name in ("bench_driver_args", "bench_default"):
 notes = {"driver_args": "python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --no-4k-leg (the driver's arguments; headline leg)",
          "4k": "python3 bench.py --workload cornell_4k_16spp_per_step --steps 64 --warmup 2 --cpu-seconds 0 --no-4k-leg (the 4K / 1024 spp leg as a run of its own)",
          "default": "python3 bench.py --cpu-seconds 0 --no-4k-leg (1024 steps)",
-         "serial": "python3 bench.py --frames-in-flight 1 --steps 128 --warmup 8 --cpu-seconds 0 --no-4k-leg"}
+         "serial": "PT_AMD_RENDER_AHEAD=0 python3 bench.py --frames-in-flight 1 --steps 128 --warmup 8 --cpu-seconds 0 --no-4k-leg (one launch per frame, strictly serial)",
+         "ahead": "python3 bench.py --frames-in-flight 1 --steps 128 --warmup 8 --cpu-seconds 0 --no-4k-leg (one frame at a time as the library runs it by default: the next frame rendered ahead)"}
 for t, note in notes.items():
+    if not glob.glob(os.path.join(src, "trace_" + t, "**", "*kernel_trace.csv"), recursive=True): continue
     tr = newest(os.path.join(src, "trace_" + t, "**", "*kernel_trace.csv"))
     st = newest(os.path.join(src, "trace_" + t, "**", "*kernel_stats.csv"))
     shutil.copy(st, os.path.join(dst, f"{prefix}_kernel_stats_{t}.csv"))

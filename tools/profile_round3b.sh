@@ -17,6 +17,9 @@ timeout -k 10 300 python3 -u $B --cpu-seconds 0 > $O/bench_default.json 2> $O/be
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_driver_args -- python3 $B $DRV --cpu-seconds 0 --no-4k-leg --no-direct-leg > $O/trace_driver_args.log 2>&1 || { echo "trace (driver args) failed"; tail -5 $O/trace_driver_args.log; exit 1; }
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_4k -- python3 $B --workload cornell_4k_16spp_per_step --steps 64 --warmup 2 --cpu-seconds 0 --no-4k-leg --no-direct-leg > $O/trace_4k.log 2>&1 || { echo "trace (4k) failed"; exit 1; }
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -- python3 $B --cpu-seconds 0 --no-4k-leg --no-direct-leg > $O/trace_default.log 2>&1 || { echo "trace (default) failed"; exit 1; }
+# (one launch per frame, strictly serial: render-ahead off for this command and for the serial PMC passes below; the same
+#  loop as the library runs it by default -- the next frame rendered ahead -- is traced after them)
+export PT_AMD_RENDER_AHEAD=0
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_serial -- python3 $B --frames-in-flight 1 --steps 128 --warmup 8 --cpu-seconds 0 --no-4k-leg --no-direct-leg > $O/trace_serial.log 2>&1 || { echo "trace (serial) failed"; exit 1; }
 # 3. PMC passes (each its own run; <= 8 SQ / 4 TCC counters per pass), serial launches so that per-dispatch numbers are per launch
 P="python3 $B --frames-in-flight 1 --steps 64 --warmup 8 --cpu-seconds 0 --no-4k-leg --no-direct-leg"
@@ -24,6 +27,8 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_wait -- $P > $O/pmc_wait.log 2>&1 || { echo "pmc wait failed"; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $P > $O/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $P > $O/pmc_write.log 2>&1 || { echo "pmc write failed"; exit 1; }
+unset PT_AMD_RENDER_AHEAD
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ahead -- python3 $B --frames-in-flight 1 --steps 128 --warmup 8 --cpu-seconds 0 --no-4k-leg --no-direct-leg > $O/trace_ahead.log 2>&1 || { echo "trace (render-ahead) failed"; exit 1; }
 # 4. the same four passes on the driver's command: its 20 timed frames are ONE launch of the path kernel (frames in flight collect
 #    them) followed by one fold pass; rocprofv3 serialises dispatches while it counts, which changes nothing for a single launch
 P2="python3 $B $DRV --cpu-seconds 0 --no-4k-leg --no-direct-leg"

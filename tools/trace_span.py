@@ -6,8 +6,10 @@ so rocprofv3's per-dispatch duration (start to end of ONE dispatch, other dispat
 `frames in flight` times the time per launch.  The like-for-like figure from a trace is first start to last end of
 the L timed dispatches / L.
 Dispatch order of pt_path_kernel in a one-leg bench run (--no-4k-leg): set-up, warm-up, the L timed launches, then (if
-frames in flight > 1) min(K, 128) strictly serial one-frame launches, then the instrumented launches (template
-argument COUNT = true, skipped here).  Fold passes (pt_fold_kernel) of the timed launches are inside the span.
+frames in flight > 1) the two one-frame-at-a-time probes of m = 4 + n frames each (4 untimed, n = min(K - 4, 128) timed):
+m strictly serial launches, then the same frames with render-ahead (2 launches on the context's stream, m - 2 launched
+ahead and used, 1 launched ahead and left: m + 1), then the instrumented launches (template argument COUNT = true,
+skipped here).  Fold passes (pt_fold_kernel) of the timed launches are inside the span.
 
   python tools/trace_span.py <kernel_trace.csv> <bench_line.json> <out.json> ["note"]
 """
@@ -23,8 +25,12 @@ path.sort(key=lambda r: int(r["Start_Timestamp"]))
 fold = sorted((r for r in rows if "pt_fold_kernel" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
 st = [int(r["Start_Timestamp"]) for r in path]; en = [int(r["End_Timestamp"]) for r in path]
 L = int(d["roofline"]["launches"])
-n_serial = min(K, 128) if F > 1 else 0
-timed = range(len(path) - n_serial - L, len(path) - n_serial)
+n_serial = max(0, min(K - 4, 128)) if F > 1 else 0      # timed frames of each probe
+m = 4 + n_serial if n_serial else 0
+c = d["config"]
+ahead_applies = c["spp_per_step"] < 4 and c["width"] * c["height"] <= (1 << 22)      # (else the second probe is m serial launches too)
+tail = (2 * m + (1 if ahead_applies else 0)) if n_serial else 0
+timed = range(len(path) - tail - L, len(path) - tail)
 first, last = min(st[i] for i in timed), max(en[i] for i in timed)
 folds_in = [r for r in fold if first <= int(r["Start_Timestamp"]) and int(r["Start_Timestamp"]) <= last + 200000]
 last_fold = max([int(r["End_Timestamp"]) for r in folds_in] + [last])
@@ -35,14 +41,21 @@ res = {"source": note, "timed_steps": K, "timed_launches": L, "steps_per_launch"
        "ns_per_step_incl_last_fold": (last_fold - first) / K,
        "mean_dispatch_duration_ns": busy / L, "mean_launches_in_flight": busy / (last - first),
        "fold_passes_in_span": len(folds_in), "mean_fold_duration_ns": (sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in folds_in) / max(len(folds_in), 1))}
-ser = range(len(path) - n_serial, len(path))
+ser = range(len(path) - tail + 4, len(path) - tail + m)
 if len(ser) > 0:
     res["serial_launches"] = len(ser)
     res["serial_ns_per_launch"] = (max(en[i] for i in ser) - min(st[i] for i in ser)) / len(ser)
     res["serial_mean_dispatch_duration_ns"] = sum(en[i] - st[i] for i in ser) / len(ser)
+    # the render-ahead probe: frame j of it (j >= 2) was launched ahead during frame j - 1, so the kernels of its timed
+    # frames 4 .. m-1 are dispatches 4 .. m-1 of the phase; the timed region ends with the fold pass of the last of them
+    ah = range(len(path) - (m + 1) + 4, len(path) - 1) if ahead_applies else range(len(path) - m + 4, len(path))
+    a_last = max(en[i] for i in ah)
+    res["render_ahead_launches"] = len(ah)
+    res["render_ahead_ns_per_frame"] = (a_last - st[ah[0]]) / len(ah)
+    res["render_ahead_mean_dispatch_duration_ns"] = sum(en[i] - st[i] for i in ah) / len(ah)
 r = d["roofline"]
 res["bench_line_of_the_same_run"] = {"value_msamples_per_s": d["value"], "ms_per_step": d["ms_per_step"], "kernel_ms": r["kernel_ms"],
-                                     "kernel_ms_serial": r.get("kernel_ms_serial"), "frac": r["frac"], "flops_per_launch": r["flops_per_launch"]}
+                                     "kernel_ms_serial": r.get("kernel_ms_serial"), "frame_ms_render_ahead": r.get("frame_ms_render_ahead"), "frac": r["frac"], "flops_per_launch": r["flops_per_launch"]}
 res["frac_from_this_trace"] = r["flops_per_launch"] / (res["ns_per_launch_incl_last_fold"] * 1e-9) / 1e12 / r["peak"]
 res["frac_path_kernels_only"] = r["flops_per_launch"] / (res["ns_per_launch_amortised"] * 1e-9) / 1e12 / r["peak"]
 res["frac_line_over_trace"] = r["frac"] / res["frac_from_this_trace"]
