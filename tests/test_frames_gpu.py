@@ -418,7 +418,8 @@ def test_render_ahead_under_random_host_behaviour():
     that reads, buffer and display are equal bit for bit."""
     import torch
     from path_tracer_amd.renderer import Renderer
-    torch.cuda.set_stream(torch.cuda.Stream())
+    before = torch.cuda.current_stream()
+    torch.cuda.set_stream(torch.cuda.Stream())      # (use_torch_stream below: a stream that is not the null stream)
     a, b = Renderer(0), Renderer(0)
     try:
         b.set_render_ahead(False)
@@ -497,3 +498,4 @@ def test_render_ahead_under_random_host_behaviour():
         assert used > 100 and launched > used and b.render_ahead_stats() == (0, 0)
     finally:
         a.close(); b.close()
+        torch.cuda.set_stream(before)
