@@ -327,7 +327,7 @@ int pt_flush(PtContext* ctx);
  * buffer (or applies the running mean's step) and makes the display, as a frame in flight is folded: buffer and
  * display are the serial loop's bit for bit.  If it is anything else -- another sample range, other parameters, a new
  * camera or scene -- the plane is dropped and the call renders as usual; render-ahead resumes when two calls
- * continue one another again.  The cost: one frame of GPU work wasted when the loop stops, and two planes of 16 B
+ * continue one another again.  The cost: one frame of GPU work wasted when the loop stops, and four planes of 16 B
  * per pixel (allocated when it first happens; a device without room for them renders serially).  On by default for
  * frames of <= 2^22 pixels and calls of < 4 samples without event counters; off with frames in flight (n > 1), which
  * do better for callers that can let the library hold frames back.  pt_render_noalloc never renders ahead.
