@@ -313,8 +313,9 @@ int pt_render_noalloc(PtContext* ctx, void* accum_float4, uint32_t width, uint32
 int pt_set_frames_in_flight(PtContext* ctx, uint32_t n);
 uint32_t pt_frames_in_flight(PtContext* ctx);
 /* Launches of the path kernel this context has made so far (frames that are held
- * back are not launched yet): lets a caller relate frames to launches when it
- * reads a profile. */
+ * back are not launched yet; a frame rendered ahead counts when a call takes it,
+ * pt_render_ahead_stats counts the others): lets a caller relate frames to
+ * launches when it reads a profile. */
 uint64_t pt_path_launches(PtContext* ctx);
 int pt_flush(PtContext* ctx);
 /* Render-ahead, for the loop that launches one frame at a time and shows it before it launches the next (the
