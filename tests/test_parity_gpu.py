@@ -1525,6 +1525,10 @@ def test_bench_line_contract():
     r = d["roofline"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1 and r["unit"] == "TFLOP/s"
     assert abs(d["value"] - 1280 * 720 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    # the same frames one at a time: strictly serial launches, and the library's default for that loop (the next frame
+    # rendered ahead), which must not be slower; both below the headline's frames in flight
+    assert 0 < r["frame_ms_render_ahead"] < r["kernel_ms_serial"] * 1.02 and r["frac_serial"] < r["frac_render_ahead"] * 1.02
+    assert r["frame_ms"] < r["frame_ms_render_ahead"]
     # the 4K leg (BASELINE config 3 at N = 1: 64 steps of 16 spp = 1024 spp)
     l = d["legs"]["cornell_4k_1024spp_strong_split"]
     assert l["spp_total"] == 1024 and l["width"] == 3840 and l["value"] > 0 and 0 < l["roofline"]["frac"] < 1
