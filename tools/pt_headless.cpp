@@ -18,7 +18,7 @@ static void usage() {
         "usage: pt_headless [--scene cuda_default|cpu_default|glass_stress|random4096] [--width W] [--height H]\n"
         "                   [--spp N] [--spp-per-launch K] [--max-depth D] [--integrator path|direct] [--seed S]\n"
         "                   [--mis] [--light-colour] [--device I] [--resume raw] [--out image.ppm] [--raw accum.f32]\n"
-        "                   [--frames-in-flight 1..8]  overlap consecutive launches (progressive rendering at few spp per launch)\n"
+        "                   [--frames-in-flight 1..8]  overlap consecutive launches (default: 2 for a render, 1 for --script; same image bit for bit)\n"
         "                   [--counters]  run the instrumented kernel: print the event counters and the path-length histogram\n"
         "                   [--script camera.txt]   lines: <frames> <mouse_dx> <mouse_dy> <keys: wasd u(p) c(down) or ->\n"
         "                                           (the CPU app's frame loop, main.cpp:153-237, 1 spp per frame;\n"
@@ -27,7 +27,7 @@ static void usage() {
 
 int main(int argc, char** argv) {
     std::string scene = "cuda_default", integrator, out, raw, resume, script;
-    uint32_t W = 1280, H = 720, spp = 64, per = 0, depth = 0, seed = 0x5EED0001u, flags = 0, flight = 1;
+    uint32_t W = 1280, H = 720, spp = 64, per = 0, depth = 0, seed = 0x5EED0001u, flags = 0, flight = 0;   // 0: not given
     int device = 0;
     bool counters = false;
     for (int i = 1; i < argc; ++i) {
@@ -66,6 +66,9 @@ int main(int argc, char** argv) {
         pt::Renderer r(device);
         r.setScene(s);
         r.setCamera(c);
+        // default: two frames in flight for a render (nothing reads the buffer between its launches), one for a scripted
+        // session (every frame is shown: the library renders the next one ahead, pt_set_render_ahead)
+        if (flight == 0) flight = script.empty() ? 2u : 1u;
         if (flight > 1) r.setFramesInFlight(flight);
         const size_t npix = (size_t)W * H;
         uint32_t begin = 0;
