@@ -137,6 +137,16 @@ struct PtContext {
     bool ahead_fold_pending[2][2] = {};                      // ... is recorded and not waited for yet
     bool ahead_fork[2] = {true, true}; // per render-ahead chain: its next launch is ordered behind the context's stream (uploads)
     uint64_t ahead_launched = 0, ahead_used = 0;   // pt_render_ahead_stats
+    // A call that the library cuts into frames by itself (own_burst) is a burst of its own, joined before the call returns.
+    // Consecutive such calls take the chains in turn (own_base rotates) and their kernels do not wait for the context's
+    // stream -- which waits for the previous call's fold passes -- unless something they read was enqueued there since
+    // (chain_needs_fork: scene, camera, frame size; a frame rendered ahead on a borrowed stream): a call's kernel fills
+    // the chip while the previous call's last paths drain (720p in calls of 16 samples: 9.4 -> 10.6 Gsamples/s, glass_stress
+    // 7.5 -> 8.1; with the context's stream among the chains 10.1 and 7.8).  The fold
+    // passes keep their order: the first of a burst waits for the context's stream as it was when the burst began.
+    uint32_t own_base = 0;
+    bool chain_needs_fork[PT_MAX_CHAINS] = {true, true, true, true, true, true, true, true};
+    bool ahead_dirty = false;          // a frame was rendered ahead since drop_ahead last ran
     uint32_t burst = 0;                // launches since the chains were last joined
     uint64_t path_launches = 0;        // launches of the path kernel since pt_create (pt_path_launches)
     bool burst_displayed = false;      // some launch of the burst asked for a display
@@ -149,6 +159,7 @@ struct PtContext {
     uint32_t resident_blocks[8] = {};  // per kernel build (nee, count, few)
     // tuning / tracing knobs for tools/gpu_ab.py and tools/gpu_trace.py, read once at pt_create
     // (PT_AMD_FEW_MAX, PT_AMD_MAX_BLOCKS, PT_AMD_GRID_PCT, PT_AMD_FRAMES, PT_AMD_CHUNK, PT_AMD_REGEN_MIN, PT_AMD_IDLE_MIN, PT_AMD_PREFETCH, PT_AMD_TRACE); -1 / empty = not set
+    bool knob_own_chain0 = false;         // PT_AMD_OWN_CHAIN0=1 (A/B): the library's own bursts use chain 0 too
     bool knob_fail_chain_alloc = false;   // PT_AMD_FAIL_CHAIN_ALLOC=1 (tests): the chains' buffers cannot be allocated
     int knob_few_max = -1, knob_max_blocks = -1, knob_chunk = -1, knob_regen_min = -1, knob_idle_min = -1, knob_prefetch = -1, knob_grid_pct = -1, knob_frames = -1;
     std::string knob_trace;
@@ -179,13 +190,28 @@ int end_shim_binding(PtContext* ctx) {
 // hardware queues keeps apart (streams of their own shared a queue with the context's stream in a process that had used
 // frames in flight before, and the frame rendered ahead then ran behind the pass it was to overlap).
 constexpr uint32_t AHEAD_CHAIN_0 = 1u;
-int drop_ahead(PtContext* ctx) {
+// `uploads`: the caller is about to change what kernels read (scene, camera, frame): the next kernel on every chain goes
+// behind the context's stream.
+int drop_ahead(PtContext* ctx, bool uploads = true) {
     for (uint32_t c = AHEAD_CHAIN_0; c < AHEAD_CHAIN_0 + 2u; ++c)
         if (ctx->chain_done[c]) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->chain_done[c], 0));   // (never recorded: no wait)
     ctx->ahead.valid = false;
     ctx->last.valid = false; ctx->last.streak = 0;
     ctx->ahead_fork[0] = ctx->ahead_fork[1] = true;
+    if (uploads || ctx->ahead_dirty)
+        for (bool& f : ctx->chain_needs_fork) f = true;
+    ctx->ahead_dirty = false;
     return PT_OK;
+}
+// Chain of launch k of the open burst.
+// (a burst of the library's own keeps off chain 0, the context's stream: a kernel there is behind the previous call's fold
+//  passes whatever it waits for)
+inline uint32_t chain_period(const PtContext* ctx) {   // launches after which the burst comes back to a chain
+    return (ctx->own_burst && ctx->flight > 2u && !ctx->knob_own_chain0) ? ctx->flight - 1u : ctx->flight;
+}
+inline uint32_t chain_of(const PtContext* ctx, uint32_t k) {
+    if (ctx->own_burst && ctx->flight > 2u && !ctx->knob_own_chain0) return 1u + (k + ctx->own_base) % (ctx->flight - 1u);
+    return (k + (ctx->own_burst ? ctx->own_base : 0u)) % ctx->flight;
 }
 
 int use(PtContext* ctx) {
@@ -248,10 +274,11 @@ constexpr size_t WORK_SET_WORDS = 256;  // 8 shards x 32 words (128 B apart)
 // kernel launch), so a fold pass is enqueued as late as it may be: when its chain is about to launch again, or when
 // the burst is joined.  The first launches of a burst therefore leave the host 3 us apart and fill the chip at once.
 int queue_next_fold(PtContext* ctx) {
-    const uint32_t k = ctx->folds_queued, chain = k % ctx->flight;
+    const uint32_t k = ctx->folds_queued, chain = chain_of(ctx, k);
     hipStream_t stream = ctx->chain_stream[chain];
     const uint32_t npix = ctx->width * ctx->height, frames = ctx->chain_frames[chain];
-    if (k > 0) PROF(ctx, 2, hipStreamWaitEvent(stream, ctx->fold_done[(k - 1u) % ctx->flight], 0));
+    if (k > 0) PROF(ctx, 2, hipStreamWaitEvent(stream, ctx->fold_done[chain_of(ctx, k - 1u)], 0));
+    else if (stream != ctx->stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->fork_event, 0));   // the buffer as the context's stream left it when the burst began
     PROF(ctx, 3, pt_launch_fold(ctx->accum, ctx->chain_acc[chain], npix, frames, ctx->fold_rgba[chain] ? (uint32_t*)ctx->display : nullptr,
                                 ctx->history, npix, ctx->chain_mode[chain], ctx->chain_s0[chain], ctx->chain_stride[chain], stream));
     PROF(ctx, 4, hipEventRecord(ctx->fold_done[chain], stream));
@@ -269,8 +296,9 @@ int join_chains(PtContext* ctx) {
     if (ctx->burst == 0) return PT_OK;
     while (ctx->folds_queued < ctx->burst)
         if (int rc = queue_next_fold(ctx)) return rc;
-    const uint32_t last = (ctx->burst - 1u) % ctx->flight;
+    const uint32_t last = chain_of(ctx, ctx->burst - 1u);
     if (ctx->chain_stream[last] != ctx->stream) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->fold_done[last], 0));  // (chain 0 is the context's stream itself)
+    if (ctx->own_burst) ctx->own_base = (ctx->own_base + ctx->burst) % (ctx->flight * (ctx->flight - 1u));   // (a multiple of both moduli of chain_of)
     ctx->burst = 0;
     ctx->folds_queued = 0;
     ctx->ahead_fork[0] = ctx->ahead_fork[1] = true;   // render-ahead shares chains 1 and 2: its next launches go behind the fold passes
@@ -438,7 +466,7 @@ int render_in_parts(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count
     const uint32_t user_flight = ctx->flight;
     PtRenderParams sub = *prm;
     if (!pipelined) {
-        if (int rc = drop_ahead(ctx)) return rc;   // the burst takes the chains that render-ahead uses
+        if (int rc = drop_ahead(ctx, false)) return rc;   // the burst takes the chains that render-ahead uses
         ctx->flight = ctx->burst_chains;
         ctx->own_burst = true;
         sub.fused_rgba8 = 0;
@@ -559,11 +587,18 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
             if (int rc = prepare_chains(ctx)) return rc;
             HIP_TRY(hipEventRecord(ctx->fork_event, ctx->stream));
         }
-        chain = ctx->burst % ctx->flight;
+        chain = chain_of(ctx, ctx->burst);
         stream = ctx->chain_stream[chain];
         // (a chain's launches and fold passes alternate on its stream: its buffer is folded before it is written again)
-        if (ctx->burst < ctx->flight && stream != ctx->stream) PROF(ctx, 0, hipStreamWaitEvent(stream, ctx->fork_event, 0));  // first launch of this chain in the burst
-        while (ctx->burst >= ctx->flight && ctx->folds_queued + ctx->flight <= ctx->burst)
+        // first launch of this chain in the burst: behind the context's stream -- always in a caller's burst, only when
+        // something the kernel reads has changed in a burst that the library made of one call (PtContext::own_base)
+        if (ctx->burst < chain_period(ctx) && stream != ctx->stream && (!ctx->own_burst || ctx->chain_needs_fork[chain])) {
+            PROF(ctx, 0, hipStreamWaitEvent(stream, ctx->fork_event, 0));
+            ctx->chain_needs_fork[chain] = false;
+        }
+        // (a chain launches again: the pass that folds its previous launch goes first -- `period` launches back)
+        const uint32_t period = chain_period(ctx);
+        while (ctx->burst >= period && ctx->folds_queued + period <= ctx->burst)
             if (int rc = queue_next_fold(ctx)) return rc;
         if (int rc = ensure_chain_buffers(ctx, chain, frames, prm->fused_rgba8 != 0)) return rc;  // (PT_NO_MEMORY: launch_pending renders serially)
     }
@@ -707,6 +742,7 @@ int launch_now(PtContext* ctx, uint32_t sample_begin, uint32_t sample_count, uin
     if (ahead) {   // counted as a launch when a call takes the frame (launch_path); nothing else of the context's state moves
         HIP_TRY(hipEventRecord(ctx->chain_done[chain], stream));
         ctx->ahead_launched_on[chain - AHEAD_CHAIN_0] = true;
+        ctx->ahead_dirty = true;
         ctx->ahead_plane[chain - AHEAD_CHAIN_0] ^= 1u;   // (launch_serial notes which plane this frame went to before the next launch moves on)
         ctx->work_parity[chain] ^= 1u;
         ctx->ahead_launched++;
@@ -861,6 +897,7 @@ int pt_create(int device_id, PtContext** out) {
     if (const char* e = getenv("PT_AMD_FEW_MAX")) ctx->knob_few_max = atoi(e);
     if (const char* e = getenv("PT_AMD_MAX_BLOCKS")) ctx->knob_max_blocks = atoi(e);
     if (const char* e = getenv("PT_AMD_TRACE")) ctx->knob_trace = e;
+    if (const char* e = getenv("PT_AMD_OWN_CHAIN0")) ctx->knob_own_chain0 = atoi(e) != 0;
     if (const char* e = getenv("PT_AMD_RENDER_AHEAD")) ctx->ahead_on = atoi(e) != 0;   // (pt_set_render_ahead's default, for A/B runs)
     if (const char* e = getenv("PT_AMD_CHUNK")) ctx->knob_chunk = atoi(e);
     if (const char* e = getenv("PT_AMD_REGEN_MIN")) ctx->knob_regen_min = atoi(e);
@@ -1383,14 +1420,14 @@ int pt_set_frames_in_flight(PtContext* ctx, uint32_t n) {
     // run at 10.3), so the request is granted up to what GPU_MAX_HW_QUEUES leaves room for: 3 with the default,
     // queues - 4 beyond it.  pt_frames_in_flight() tells the caller what it got.
     ctx->flight = n < ctx->burst_chains ? n : ctx->burst_chains;
-    if (ctx->flight > 1u) return drop_ahead(ctx);   // frames in flight take over from render-ahead
+    if (ctx->flight > 1u) return drop_ahead(ctx, false);   // frames in flight take over from render-ahead
     return PT_OK;
 }
 
 int pt_set_render_ahead(PtContext* ctx, uint32_t on) {
     if (int rc = use(ctx)) return rc;
     ctx->ahead_on = on != 0u;
-    return on ? PT_OK : drop_ahead(ctx);
+    return on ? PT_OK : drop_ahead(ctx, false);
 }
 
 int pt_render_ahead_stats(PtContext* ctx, uint64_t* launched, uint64_t* used) {
