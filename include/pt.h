@@ -330,8 +330,9 @@ int pt_flush(PtContext* ctx);
  * camera or scene -- the plane is dropped and the call renders as usual; render-ahead resumes when two calls
  * continue one another again.  The cost: one frame of GPU work wasted when the loop stops, and four planes of 16 B
  * per pixel (allocated when it first happens; a device without room for them renders serially).  On by default for
- * frames of <= 2^22 pixels and calls of < 4 samples without event counters; off with frames in flight (n > 1), which
- * do better for callers that can let the library hold frames back.  pt_render_noalloc never renders ahead.
+ * every call that is one launch of its own -- fewer than 4 samples, or any number on a frame of more than 2^22 pixels
+ * (see "Large calls") -- on frames of up to 2^24 pixels, without event counters; off with frames in flight (n > 1),
+ * which do better for callers that can let the library hold frames back.  pt_render_noalloc never renders ahead.
  * `on` = 0 turns it off (strictly one launch per call, the previous call's kernel ended before the next begins).
  * pt_render_ahead_stats: frames launched ahead so far, and how many of them a call then used.
  * No counterpart in the reference. */

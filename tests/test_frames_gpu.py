@@ -394,6 +394,18 @@ def test_render_ahead_gives_the_serial_loops_bits(gpu):
     gpu.set_camera(cam2); gpu.reset()
     for k in range(4, 8): gpu.render(k, 1, p)
     assert np.array_equal(got, gpu.accum())
+    # a frame of more than 2^22 pixels, where a call of any sample count is one launch (and is rendered ahead as such)
+    big_sc, big_cam = scenes.cuda_default(2100, 2000)
+    q = abi.render_params(max_depth=6, fused_rgba8=1)
+    got = {}
+    for on in (False, True):
+        gpu.set_render_ahead(on)
+        _setup(gpu, big_sc, big_cam)
+        u0 = gpu.render_ahead_stats()[1]
+        for k in range(5): gpu.render(k * 5, 5, q)
+        got[on] = (gpu.accum(), gpu.readback(abi.RESOLVE_RGBA8_CUDA), gpu.render_ahead_stats()[1] - u0)
+    assert np.array_equal(got[True][0], got[False][0]) and np.array_equal(got[True][1], got[False][1])
+    assert got[True][2] == 3 and got[False][2] == 0 and np.all(got[True][0][..., 3] == 25)
     # launchRenderKernel, the reference's loop: launch, read `output`, launch
     _setup(gpu, sc, cam)
     out_a = torch.zeros((108, 192, 4), device="cuda", dtype=torch.float32)

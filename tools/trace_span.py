@@ -28,7 +28,8 @@ L = int(d["roofline"]["launches"])
 n_serial = max(0, min(K - 4, 128)) if F > 1 else 0      # timed frames of each probe
 m = 4 + n_serial if n_serial else 0
 c = d["config"]
-ahead_applies = c["spp_per_step"] < 4 and c["width"] * c["height"] <= (1 << 22)      # (else the second probe is m serial launches too)
+npix_ = c["width"] * c["height"]
+ahead_applies = (c["spp_per_step"] < 4 or npix_ > (1 << 22)) and npix_ <= (1 << 24)      # the calls render-ahead takes (launch_serial, pt_api.cpp); else the second probe is m serial launches too
 tail = (2 * m + (1 if ahead_applies else 0)) if n_serial else 0
 timed = range(len(path) - tail - L, len(path) - tail)
 first, last = min(st[i] for i in timed), max(en[i] for i in timed)
