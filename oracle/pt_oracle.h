@@ -26,8 +26,14 @@
  * output of the CUDA program the reference holds, images/cuda.png (a screenshot of
  * its default scene): the `path` restatement reproduces it to a few 8-bit levels
  * (fixture tests/golden/reference_cuda_screenshot_480x270.npz).  That is an
- * image-level pin (8 bits, unknown sample count); individual formulas of the `path`
- * integrator and the `direct` light term remain "parity unpinned" beyond it.
+ * image-level pin (8 bits, unknown sample count); (3) the one output of the CPU program
+ * it holds, images/cpu.png (a grab at one sample per pixel; tests/cpu_screenshot.py,
+ * fixture tests/golden/reference_cpu_screenshot_711x1270.npz): the `direct`
+ * restatement puts every object where the grab shows it, gives the grab's light term
+ * pixel by pixel on both coloured walls and its bytes wherever a pixel shows two
+ * unsaturated channels of one light sample.  Which `direct` light samples come out
+ * visible (FP rounding of the reference's -ffast-math build) and the
+ * individual formulas of the `path` integrator remain "parity unpinned" beyond these.
  */
 #ifndef PT_ORACLE_H_
 #define PT_ORACLE_H_

@@ -183,6 +183,28 @@ def test_direct_config0_64spp_statistics(gpu, oracle):
     assert cpu8.shape == (90, 160) and cpu8.max() <= 0xFFFFFF
 
 
+def test_direct_against_the_references_own_cpu_screenshot(gpu):
+    """The HIP `direct` kernel, the FP64 id pass and the CPU-style resolve against images/cpu.png, the reference's own grab
+    of its CPU app at one sample per pixel (tests/cpu_screenshot.py; the oracle passes the same checks in
+    tests/test_oracle_pins.py): the unlit byte, every object's place on the screen, the light term pixel by pixel on both
+    coloured walls, the pixel formula where the bright channel is not saturated, the shadows."""
+    from tests import cpu_screenshot as cs
+    sc, cam = cs.scene_and_camera()
+    p = abi.render_params(integrator=abi.INTEGRATOR_DIRECT)
+    _setup(gpu, sc, cam)
+    ids = gpu.primary_ids()[0]
+    frames = []
+    for s in range(16):
+        gpu.reset()
+        gpu.render(s, 1, p)
+        frames.append(gpu.resolve_to_host(abi.RESOLVE_RGBA8_CPU).copy())
+
+    def record(key, value):
+        _MEASURED[f"cpu_screenshot/{key}"] = {"measured": float(value), "limit": None, "kind": "info"}
+    got = cs.check(frames, ids, record)
+    assert got["lit_pixels_on_another_object"] < 100 and got["sphere_0.7_0.3/bright_bytes_compared"] > 100
+
+
 # ----------------------------------------------------------------- T3: path integrator ---
 def _frac_differing(gm, wm, tol=1e-3):
     return float((np.abs(gm - wm).max(axis=2) > tol * (1.0 + np.abs(wm).max(axis=2))).mean())
