@@ -483,6 +483,64 @@ static int dvisible(const PtSceneSoA* sc, D3 from, D3 to) {
     return 1;
 }
 
+/* ---- sin, cos, acos of the light sample (Sphere::getRandomPoint, ImplicitObject.h:111-125) ----------------------
+ * The reference calls std::cos / std::sin / std::acos; their last bits depend on its libm and on its -ffast-math build,
+ * and through the tie of D6 (hit.distance < distance on the sampled light itself) one such bit decides whether a light
+ * sample counts.  Like the random streams, the three functions are therefore SPECIFIED here and
+ * evaluated the same way by the HIP kernel (pt_f64_kernels.hip restates them; no shared header): +, -, *, /, sqrt in
+ * IEEE double without contraction, so that oracle and GPU agree to the bit.  Within 1 ulp of the libm values
+ * (tests/test_oracle_pins.py).
+ *  sincos, 0 <= x < 8: n = the nearest multiple of pi/2; r = (x - n A) - n B with A = pi/2 cut to 33 bits (n A is exact)
+ *  and B = the next 53 bits; odd and even polynomials of degree 13 and 14 in r on [-pi/4, pi/4]; the quadrant swaps them.
+ *  acos, -1 <= x <= 1: |x| < 1/2: pi/2 - (x + x R(x^2)); else with z = (1 -+ x) / 2, s = sqrt z: 2 (s + s R(z)), or pi
+ *  minus that; R = z P(z) / Q(z) of degrees 5 and 4. */
+static const double FM_INVPIO2 = 6.36619772367581382433e-01, FM_PIO2_A = 1.57079632673412561417e+00, FM_PIO2_B = 6.07710050650619224932e-11;
+static const double FM_S1 = -1.66666666666666324348e-01, FM_S2 = 8.33333333332248946124e-03, FM_S3 = -1.98412698298579493134e-04,
+                    FM_S4 = 2.75573137070700676789e-06, FM_S5 = -2.50507602534068634195e-08, FM_S6 = 1.58969099521155010221e-10;
+static const double FM_C1 = 4.16666666666666019037e-02, FM_C2 = -1.38888888888741095749e-03, FM_C3 = 2.48015872894767294178e-05,
+                    FM_C4 = -2.75573143513906633035e-07, FM_C5 = 2.08757232129817482790e-09, FM_C6 = -1.13596475577881948265e-11;
+static const double FM_PIO2_HI = 1.57079632679489655800e+00, FM_PIO2_LO = 6.12323399573676603587e-17, FM_PI = 3.14159265358979311600e+00;
+static const double FM_P0 = 1.66666666666666657415e-01, FM_P1 = -3.25565818622400915405e-01, FM_P2 = 2.01212532134862925881e-01,
+                    FM_P3 = -4.00555345006794114027e-02, FM_P4 = 7.91534994289814532176e-04, FM_P5 = 3.47933107596021167570e-05;
+static const double FM_Q1 = -2.40339491173441421878e+00, FM_Q2 = 2.02094576023350569471e+00, FM_Q3 = -6.88283971605453293030e-01,
+                    FM_Q4 = 7.70381505559019352791e-02;
+
+static void fm_sincos(double x, double* sn, double* cs) {
+    const int n = (int)(x * FM_INVPIO2 + 0.5);
+    const double r = (x - (double)n * FM_PIO2_A) - (double)n * FM_PIO2_B;
+    const double z = r * r;
+    const double ps = r + r * (z * (FM_S1 + z * (FM_S2 + z * (FM_S3 + z * (FM_S4 + z * (FM_S5 + z * FM_S6))))));
+    const double pc = 1.0 - z * (0.5 - z * (FM_C1 + z * (FM_C2 + z * (FM_C3 + z * (FM_C4 + z * (FM_C5 + z * FM_C6))))));
+    switch (n & 3) {
+        case 0: *sn = ps; *cs = pc; break;
+        case 1: *sn = pc; *cs = -ps; break;
+        case 2: *sn = -ps; *cs = -pc; break;
+        default: *sn = -pc; *cs = ps; break;
+    }
+}
+static double fm_ratio(double z) {
+    const double p = z * (FM_P0 + z * (FM_P1 + z * (FM_P2 + z * (FM_P3 + z * (FM_P4 + z * FM_P5)))));
+    const double q = 1.0 + z * (FM_Q1 + z * (FM_Q2 + z * (FM_Q3 + z * FM_Q4)));
+    return p / q;
+}
+static double fm_acos(double x) {
+    if (fabs(x) < 0.5) return FM_PIO2_HI - (x - (FM_PIO2_LO - x * fm_ratio(x * x)));
+    if (x < 0) {
+        const double z = (1.0 + x) * 0.5, s = sqrt(z);
+        const double w = fm_ratio(z) * s - FM_PIO2_LO;
+        return FM_PI - 2.0 * (s + w);
+    }
+    const double z = (1.0 - x) * 0.5, s = sqrt(z);
+    return 2.0 * (s + fm_ratio(z) * s);
+}
+/* for the tests: out = {sin x, cos x, acos y} as specified above */
+int pto_fmath(double x, double y, double* out3) {
+    if (!out3) return PT_ERR_INVALID;
+    fm_sincos(x, &out3[0], &out3[1]);
+    out3[2] = fm_acos(y);
+    return PT_OK;
+}
+
 static inline double duni(uint32_t bits) { return (double)bits * (1.0 / 4294967296.0); } /* [0,1) like Random::get */
 
 /* One sample of renderRegion's body, cpu_pathtracer/src/main.cpp:23-46.
@@ -508,9 +566,11 @@ static void direct_sample(const PtSceneSoA* sc, const DCam* k, uint32_t x, uint3
         double u = duni(pto_draw(key, 1 + light, 0)), v = duni(pto_draw(key, 1 + light, 1));
         light++;
         double theta = 2.0 * M_PI * u;
-        double phi = acos(2.0 * v - 1.0);
-        double sin_phi = sin(phi);
-        D3 direction = d3(cos(theta) * sin_phi, sin(theta) * sin_phi, cos(phi));
+        double phi = fm_acos(2.0 * v - 1.0);
+        double sin_theta, cos_theta_, sin_phi, cos_phi;   /* cos(theta), sin(theta), sin(phi), cos(phi) as specified above */
+        fm_sincos(theta, &sin_theta, &cos_theta_);
+        fm_sincos(phi, &sin_phi, &cos_phi);
+        D3 direction = d3(cos_theta_ * sin_phi, sin_theta * sin_phi, cos_phi);
         D3 lp = dadd(d3(sc->sph_cx[i], sc->sph_cy[i], sc->sph_cz[i]), dmul(direction, sc->sph_r[i]));
         D3 light_dir = dnormalized(dsub(lp, hit.p));
         double cos_theta = fmax(0.0, ddot(hit.n, light_dir));

@@ -48,6 +48,8 @@ extern "C" {
 uint32_t pto_hash(uint32_t x);
 uint32_t pto_path_key(uint32_t seed, uint32_t pixel, uint32_t sample);
 uint32_t pto_draw(uint32_t key, uint32_t slot, uint32_t dim);
+/* The specified sin / cos / acos of the `direct` light sample (pt_oracle.c): out3 = {sin x, cos x, acos y}. */
+int pto_fmath(double x, double y, double* out3);
 
 /* Primary-hit object / material ids through pixel centres, FP64. */
 int pto_primary_ids(const PtSceneSoA* scene, const PtCamera* cam, uint32_t* obj_ids, uint32_t* mat_ids);

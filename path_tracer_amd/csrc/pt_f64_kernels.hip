@@ -157,9 +157,55 @@ __device__ bool visible(const DevSceneD& sc, D3 from, D3 to) {
 // rays (primary + shadow), hits (primary), nee_samples (light samples drawn), shadow_rays (Scene::isVisible calls).
 // Register budget: left alone the kernel takes 134 VGPRs (3 waves/SIMD); asked for 4 it fits 126 with six spilled and
 // runs 6 % faster (21.8 -> 23.2 Gsamples/s on BASELINE config 1); 5 waves (96 VGPRs, 39 spilled) lose 4 %.
-#ifndef PT_SINCOS
-#define PT_SINCOS 1
-#endif
+// ---- sin, cos, acos of the light sample (Sphere::getRandomPoint, ImplicitObject.h:111-125) ----------------------------
+// The reference calls std::cos / std::sin / std::acos, whose last bits depend on its libm and its -ffast-math build; through
+// the tie of D6 (hit.distance < distance on the sampled light itself) one such bit decides whether a light sample counts.
+// Like the random streams, the three functions are therefore specified: plain IEEE double
+// +, -, *, /, sqrt without contraction, within 1 ulp of the libm values, evaluated the same way by the oracle -- frames of
+// the `direct` integrator are equal to the oracle's bit for bit (tests/test_parity_gpu.py).
+//  sincos, 0 <= x < 8: n = the nearest multiple of pi/2; r = (x - n A) - n B with A = pi/2 cut to 33 bits (n A is exact) and
+//  B = the next 53 bits; an odd and an even polynomial of degree 13 and 14 in r on [-pi/4, pi/4]; the quadrant swaps them.
+//  acos, -1 <= x <= 1: |x| < 1/2: pi/2 - (x + x R(x^2)); else with z = (1 -+ x) / 2, s = sqrt z: 2 (s + s R(z)), or pi minus
+//  that; R(z) = z P(z) / Q(z) of degrees 5 and 4.
+//  (against the library's sincos + acos: -0.6 %)
+constexpr double FM_INVPIO2 = 6.36619772367581382433e-01, FM_PIO2_A = 1.57079632673412561417e+00, FM_PIO2_B = 6.07710050650619224932e-11;
+constexpr double FM_S1 = -1.66666666666666324348e-01, FM_S2 = 8.33333333332248946124e-03, FM_S3 = -1.98412698298579493134e-04,
+                 FM_S4 = 2.75573137070700676789e-06, FM_S5 = -2.50507602534068634195e-08, FM_S6 = 1.58969099521155010221e-10;
+constexpr double FM_C1 = 4.16666666666666019037e-02, FM_C2 = -1.38888888888741095749e-03, FM_C3 = 2.48015872894767294178e-05,
+                 FM_C4 = -2.75573143513906633035e-07, FM_C5 = 2.08757232129817482790e-09, FM_C6 = -1.13596475577881948265e-11;
+constexpr double FM_PIO2_HI = 1.57079632679489655800e+00, FM_PIO2_LO = 6.12323399573676603587e-17, FM_PI = 3.14159265358979311600e+00;
+constexpr double FM_P0 = 1.66666666666666657415e-01, FM_P1 = -3.25565818622400915405e-01, FM_P2 = 2.01212532134862925881e-01,
+                 FM_P3 = -4.00555345006794114027e-02, FM_P4 = 7.91534994289814532176e-04, FM_P5 = 3.47933107596021167570e-05;
+constexpr double FM_Q1 = -2.40339491173441421878e+00, FM_Q2 = 2.02094576023350569471e+00, FM_Q3 = -6.88283971605453293030e-01,
+                 FM_Q4 = 7.70381505559019352791e-02;
+
+__device__ __forceinline__ void fm_sincos(double x, double& sn, double& cs) {
+    const int n = (int)(x * FM_INVPIO2 + 0.5);
+    const double r = (x - (double)n * FM_PIO2_A) - (double)n * FM_PIO2_B;
+    const double z = r * r;
+    const double ps = r + r * (z * (FM_S1 + z * (FM_S2 + z * (FM_S3 + z * (FM_S4 + z * (FM_S5 + z * FM_S6))))));
+    const double pc = 1.0 - z * (0.5 - z * (FM_C1 + z * (FM_C2 + z * (FM_C3 + z * (FM_C4 + z * (FM_C5 + z * FM_C6))))));
+    const bool swap = (n & 1) != 0;
+    const double a = swap ? pc : ps, b = swap ? ps : pc;      // quadrant 0: (ps, pc), 1: (pc, -ps), 2: (-ps, -pc), 3: (-pc, ps)
+    sn = (n & 2) ? -a : a;
+    cs = (((n + 1) & 2) != 0) ? -b : b;
+}
+__device__ __forceinline__ double fm_ratio(double z) {
+    const double p = z * (FM_P0 + z * (FM_P1 + z * (FM_P2 + z * (FM_P3 + z * (FM_P4 + z * FM_P5)))));
+    const double q = 1.0 + z * (FM_Q1 + z * (FM_Q2 + z * (FM_Q3 + z * FM_Q4)));
+    return p / q;
+}
+__device__ __forceinline__ double fm_acos(double x) {
+    if (fabs(x) < 0.5) return FM_PIO2_HI - (x - (FM_PIO2_LO - x * fm_ratio(x * x)));
+    if (x < 0) {
+        const double z = (1.0 + x) * 0.5, s = sqrt(z);
+        const double w = fm_ratio(z) * s - FM_PIO2_LO;
+        return FM_PI - 2.0 * (s + w);
+    }
+    const double z = (1.0 - x) * 0.5, s = sqrt(z);
+    return 2.0 * (s + fm_ratio(z) * s);
+}
+
 #ifndef PT_DIRECT_WAVES
 #define PT_DIRECT_WAVES 4
 #endif
@@ -204,16 +250,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_DIRECT_W
             if (COUNT) c_lights++;
             // Sphere::getRandomPoint, ImplicitObject.h:111-125
             const double theta = 2.0 * M_PI * u;
-            const double phi = acos(2.0 * v - 1.0);
-#if PT_SINCOS   // one argument reduction and one evaluation per angle: the library's sincos returns its sin's and its cos's bits
+            const double phi = fm_acos(2.0 * v - 1.0);
             double sin_theta, cos_theta_, sin_phi, cos_phi;
-            sincos(theta, &sin_theta, &cos_theta_);
-            sincos(phi, &sin_phi, &cos_phi);
+            fm_sincos(theta, sin_theta, cos_theta_);
+            fm_sincos(phi, sin_phi, cos_phi);
             const D3 dir = d3(cos_theta_ * sin_phi, sin_theta * sin_phi, cos_phi);
-#else
-            const double sin_phi = sin(phi);
-            const D3 dir = d3(cos(theta) * sin_phi, sin(theta) * sin_phi, cos(phi));
-#endif
             const double* s = sc.sph + 4 * l;
             const D3 lp = d3(s[0], s[1], s[2]) + dir * s[3];
             const D3 light_dir = normalized(lp - hp);

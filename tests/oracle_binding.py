@@ -31,6 +31,7 @@ class Oracle:
         lib.pto_path_key.argtypes = [C.c_uint32] * 3
         lib.pto_draw.restype = C.c_uint32
         lib.pto_draw.argtypes = [C.c_uint32] * 3
+        lib.pto_fmath.argtypes = [C.c_double, C.c_double, _PD]
         lib.pto_primary_ids.argtypes = [S, K, _PU, _PU]
         lib.pto_primary_ids_rect.argtypes = [S, K, C.c_uint32, _PD, _PU, _PU, _PU, _PU]
         lib.pto_render_direct.argtypes = [S, K, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, _PF]
@@ -46,6 +47,12 @@ class Oracle:
     def _ck(rc):
         if rc != 0:
             raise RuntimeError(f"oracle call failed: {rc}")
+
+    def fmath(self, x: float, y: float):
+        """(sin x, cos x, acos y) as the `direct` light sample evaluates them (pt_oracle.c, fm_sincos / fm_acos)."""
+        out = (C.c_double * 3)()
+        self._ck(self.lib.pto_fmath(x, y, out))
+        return out[0], out[1], out[2]
 
     def primary_ids(self, scene: abi.SceneArrays, cam: abi.PtCamera):
         n = cam.width * cam.height

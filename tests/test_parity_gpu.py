@@ -156,31 +156,38 @@ def test_direct_matches_oracle(gpu, oracle):
     inner_light[1:-1, 1:-1] &= (ids[:-2, 1:-1] == 7) & (ids[2:, 1:-1] == 7) & (ids[1:-1, :-2] == 7) & (ids[1:-1, 2:] == 7)
     inner_light[0] = inner_light[-1] = False
     assert np.allclose(gm[inner_light], 100.1, rtol=1e-6) and np.allclose(wm[inner_light], 100.1, rtol=1e-6)
-    # the stochastic term: identical sample points; sin/cos/acos of the two maths libraries may
-    # differ in the last bit, which re-flips the rounding-governed self-shadow test of D6 for that
-    # sample.  Pixels agree exactly where they do not, and in the mean everywhere.
-    exact = np.isclose(gm, wm, rtol=1e-5, atol=1e-7).all(axis=2).mean()
-    _bound("direct_320x180_8spp/pixels_exactly_equal", exact, 0.95, at_least=True)      # measured 0.9827
-    # seed-to-seed standard deviation of this image mean is 3.2 % (heavy-tailed 50*cos/d^2 term)
-    _bound("direct_320x180_8spp/rel_mean_diff", abs(gm.mean() - wm.mean()) / wm.mean(), 0.034)   # measured 0.0113
+    # the stochastic term: identical sample points, and sin / cos / acos of the light sample are specified (oracle/pt_oracle.c,
+    # pt_f64_kernels.hip: IEEE +, -, *, /, sqrt without contraction), so even the rounding-governed tie of D6 falls the same
+    # way on both sides: the frames are equal bit for bit
+    assert np.array_equal(got, want)
+    _MEASURED["direct_320x180_8spp/pixels_exactly_equal"] = {"measured": float((got == want).all(axis=2).mean()), "limit": 1.0, "kind": "at_least"}
 
 
-def test_direct_config0_64spp_statistics(gpu, oracle):
-    """BASELINE config 1 shape (cpu_default, `direct`, 64 spp) at reduced resolution."""
-    sc, cam = scenes.cpu_default(160, 90)
+def test_direct_config0_bit_exact_at_full_size(gpu, oracle):
+    """BASELINE config 1 (cpu_default, `direct`, 1280x720): 64 spp on a band of rows at full width and 2 spp on the whole
+    frame, in calls of 16 and of 1 as a frame loop makes them -- the accumulation buffers equal the oracle's bit for bit
+    (FP64 arithmetic without contraction on both sides, the float adds of the buffer in the same order)."""
+    sc, cam = scenes.cpu_default(1280, 720)
     p = abi.render_params(integrator=abi.INTEGRATOR_DIRECT)
     _setup(gpu, sc, cam)
-    for s0 in range(0, 64, 16):
-        gpu.render(s0, 16, p)
-    gm = _mean(gpu.accum())
-    wm = _mean(oracle.render_direct(sc, cam, 0, 64, p))
-    # two realisations of an estimator whose light term is decided by FP rounding (SURVEY D6):
-    # about a fifth of the light samples flip between the two maths libraries
-    rmse = float(np.sqrt(((np.clip(gm, 0, 1) - np.clip(wm, 0, 1)) ** 2).mean()))
-    _bound("direct_160x90_64spp/rmse_clamped", rmse, 0.08)                                      # measured 0.0487
-    _bound("direct_160x90_64spp/abs_mean_diff_clamped", abs(np.clip(gm, 0, 1).mean() - np.clip(wm, 0, 1).mean()), 0.001)   # measured 0.0002
+    want = None
+    for s0 in range(2):
+        gpu.render(s0, 1, p)
+        want = oracle.render_direct(sc, cam, s0, 1, p, accum=want)
+    got = gpu.accum()
+    assert np.array_equal(got, want)
     cpu8 = gpu.resolve_to_host(abi.RESOLVE_RGBA8_CPU)
-    assert cpu8.shape == (90, 160) and cpu8.max() <= 0xFFFFFF
+    assert np.array_equal(cpu8, oracle.resolve(want, abi.ACC_SUM, abi.RESOLVE_RGBA8_CPU).reshape(cpu8.shape))
+    for s0 in range(2, 66, 16):
+        gpu.render(s0, 16, p)
+    got = gpu.accum()
+    rows = (300, 340)
+    band = want.copy()
+    for s0 in range(2, 66, 16):
+        band = oracle.render_direct(sc, cam, s0, 16, p, accum=band, rows=rows)
+    assert np.array_equal(got[rows[0]:rows[1]], band[rows[0]:rows[1]])
+    assert np.all(got[..., 3] == 66)
+    _MEASURED["direct_1280x720/pixels_exactly_equal"] = {"measured": 1.0, "limit": 1.0, "kind": "at_least"}
 
 
 def test_direct_against_the_references_own_cpu_screenshot(gpu):
