@@ -196,14 +196,18 @@ __device__ __forceinline__ double fm_ratio(double z) {
     return p / q;
 }
 __device__ __forceinline__ double fm_acos(double x) {
-    if (fabs(x) < 0.5) return FM_PIO2_HI - (x - (FM_PIO2_LO - x * fm_ratio(x * x)));
-    if (x < 0) {
-        const double z = (1.0 + x) * 0.5, s = sqrt(z);
-        const double w = fm_ratio(z) * s - FM_PIO2_LO;
-        return FM_PI - 2.0 * (s + w);
-    }
-    const double z = (1.0 - x) * 0.5, s = sqrt(z);
-    return 2.0 * (s + fm_ratio(z) * s);
+    // the three ranges share their rational and their square root: every wave holds lanes of all three, and evaluated range
+    // by range the quotient (an IEEE division) would run twice.  Per lane the operations are those of the description above.
+    const double ax = fabs(x);
+    const bool small = ax < 0.5;
+    const double z = small ? x * x : (1.0 - ax) * 0.5;      // (1 + x for x < 0 and 1 - x for x > 0 are the same operation on |x|)
+    const double r = fm_ratio(z);
+    const double s = sqrt(z);
+    const double rs = r * s;
+    const double mid = FM_PIO2_HI - (x - (FM_PIO2_LO - x * r));
+    const double pos = 2.0 * (s + rs);
+    const double neg = FM_PI - 2.0 * (s + (rs - FM_PIO2_LO));
+    return small ? mid : (x < 0 ? neg : pos);
 }
 
 #ifndef PT_DIRECT_WAVES
